@@ -1,0 +1,136 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so) and, when built, the real reference
+library (oracle/_ref/libedsref.so).  TEST INFRASTRUCTURE: imported by tests/, bench.py's
+cpu_baseline leg and __graft_entry__.smoke() only — never by edsparser_amd/."""
+import ctypes
+import os
+import subprocess
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class VcfStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in
+                ("total_variants", "processed_variants", "skipped_malformed",
+                 "skipped_unsupported_sv", "variant_groups")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build_oracle():
+    """Compile oracle/ (and oracle/_ref when /root/reference is present)."""
+    subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
+
+
+_lib = None
+_ref = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        so = os.path.join(_ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(so):
+            build_oracle()
+        _lib = ctypes.CDLL(so)
+        _lib.oracle_free.argtypes = [ctypes.c_void_p]
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_ORACLE_DIR, "_ref", "libedsref.so"))
+
+
+def _load_ref():
+    global _ref
+    if _ref is None:
+        _ref = ctypes.CDLL(os.path.join(_ORACLE_DIR, "_ref", "libedsref.so"))
+        _ref.ref_free.argtypes = [ctypes.c_void_p]
+    return _ref
+
+
+def _buf(b):
+    if b is None:
+        return None, 0
+    b = bytes(b)
+    return ctypes.create_string_buffer(b, len(b)) if len(b) else ctypes.create_string_buffer(1), len(b)
+
+
+def _take(free, p, n):
+    data = ctypes.string_at(p, n.value) if n.value else b""
+    free(p)
+    return data
+
+
+def _call(fn, free, args_pre, n_out=2, extra=()):
+    outs = [(ctypes.c_void_p(), ctypes.c_size_t()) for _ in range(n_out)]
+    err = ctypes.create_string_buffer(512)
+    flat = []
+    for p, n in outs:
+        flat += [ctypes.byref(p), ctypes.byref(n)]
+    rc = fn(*args_pre, *flat, *extra, err, ctypes.c_size_t(512))
+    if rc != 0:
+        raise OracleError(rc, err.value.decode(errors="replace"))
+    return [_take(free, p, n) for p, n in outs]
+
+
+def msa(file_bytes, l=0):
+    lib = _load()
+    b, n = _buf(file_bytes)
+    return tuple(_call(lib.oracle_msa, lib.oracle_free, [b, ctypes.c_size_t(n), ctypes.c_uint32(l)]))
+
+
+def msa_slab(file_bytes, c0, c1):
+    lib = _load()
+    b, n = _buf(file_bytes)
+    return tuple(_call(lib.oracle_msa_slab, lib.oracle_free,
+                       [b, ctypes.c_size_t(n), ctypes.c_uint64(c0), ctypes.c_uint64(c1)]))
+
+
+def merge(eds, seds=None, l=1, compact=True):
+    lib = _load()
+    e, en = _buf(eds)
+    s, sn = _buf(seds)
+    return tuple(_call(lib.oracle_merge, lib.oracle_free,
+                       [e, ctypes.c_size_t(en), s, ctypes.c_size_t(sn), ctypes.c_uint32(l),
+                        ctypes.c_int(1 if compact else 0)]))
+
+
+def vcf(vcf_bytes, fasta_bytes, l=0):
+    lib = _load()
+    v, vn = _buf(vcf_bytes)
+    f, fn = _buf(fasta_bytes)
+    st = VcfStats()
+    e, s = _call(lib.oracle_vcf, lib.oracle_free,
+                 [v, ctypes.c_size_t(vn), f, ctypes.c_size_t(fn), ctypes.c_uint32(l)],
+                 extra=(ctypes.byref(st),))
+    return e, s, st.as_dict()
+
+
+# ---- the real reference (build container only; merge + VCF paths) ----
+
+def ref_merge(eds, seds=None, l=1, compact=True, threads=1):
+    lib = _load_ref()
+    e, en = _buf(eds)
+    s, sn = _buf(seds)
+    return tuple(_call(lib.ref_merge, lib.ref_free,
+                       [e, ctypes.c_size_t(en), s, ctypes.c_size_t(sn), ctypes.c_uint32(l),
+                        ctypes.c_int(1 if compact else 0), ctypes.c_int(threads)]))
+
+
+def ref_vcf(vcf_bytes, fasta_bytes, l=0):
+    lib = _load_ref()
+    v, vn = _buf(vcf_bytes)
+    f, fn = _buf(fasta_bytes)
+    st = VcfStats()
+    e, s = _call(lib.ref_vcf, lib.ref_free,
+                 [v, ctypes.c_size_t(vn), f, ctypes.c_size_t(fn), ctypes.c_uint32(l)],
+                 extra=(ctypes.byref(st),))
+    return e, s, st.as_dict()
