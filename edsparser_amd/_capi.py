@@ -1,0 +1,170 @@
+"""ctypes bindings of include/edsx.h."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+STATUS = {0: "OK", 1: "FILE_NOT_FOUND", 2: "INVALID_FORMAT", 3: "INVALID_PARAMETER",
+          4: "BUILD_FAILED", 5: "QUERY_FAILED", 99: "UNKNOWN_ERROR"}
+
+
+class EdsxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (STATUS.get(code, code), msg))
+        self.code = code
+        self.message = msg
+
+
+class _Buf(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("size", ctypes.c_size_t)]
+
+
+class VcfStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in
+                ("total_variants", "processed_variants", "skipped_malformed",
+                 "skipped_unsupported_sv", "variant_groups")]
+
+
+class MsaInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in
+                ("n_rows", "n_cols", "line_width", "n_variant_cols", "n_segments", "msa_bytes")]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libedsx.so")
+
+
+def load_library():
+    """Load libedsx.so; fails loudly when the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # torch bundles its own HIP runtime (same SONAME libamdhip64.so.7): it must be the first one
+    # mapped, so that libedsx.so binds to it instead of bringing a second runtime into the process
+    import torch  # noqa: F401
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError("libedsx.so is missing: build it with `python -m edsparser_amd.build` "
+                          "(there is no CPU fallback)")
+    lib = ctypes.CDLL(path)
+    P = ctypes.POINTER
+    lib.edsx_version.restype = ctypes.c_char_p
+    lib.edsx_ctx_create.argtypes = [ctypes.c_int, P(ctypes.c_void_p)]
+    lib.edsx_ctx_destroy.argtypes = [ctypes.c_void_p]
+    lib.edsx_last_error.argtypes = [ctypes.c_void_p]
+    lib.edsx_last_error.restype = ctypes.c_char_p
+    lib.edsx_buf_free.argtypes = [P(_Buf)]
+    lib.edsx_msa_transform.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32,
+                                       P(_Buf), P(_Buf)]
+    lib.edsx_leds_merge.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                    ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, P(_Buf), P(_Buf)]
+    lib.edsx_vcf_transform.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                       ctypes.c_size_t, ctypes.c_uint32, P(_Buf), P(_Buf), P(VcfStats)]
+    lib.edsx_msa_plan_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                         ctypes.c_void_p, P(ctypes.c_uint64), P(ctypes.c_uint64)]
+    lib.edsx_msa_emit_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.edsx_msa_last_info.argtypes = [ctypes.c_void_p, P(MsaInfo)]
+    lib.edsx_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.edsx_get_timing.argtypes = [ctypes.c_void_p, P(ctypes.c_char_p), P(ctypes.c_float), ctypes.c_int]
+    lib.edsx_msa_synth_size.argtypes = [ctypes.c_uint32, ctypes.c_uint64]
+    lib.edsx_msa_synth_size.restype = ctypes.c_size_t
+    lib.edsx_msa_synth_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                          ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double, ctypes.c_uint64,
+                                          ctypes.c_void_p, P(ctypes.c_size_t)]
+    _LIB = lib
+    return lib
+
+
+def synth_size(n_rows, n_cols):
+    return int(load_library().edsx_msa_synth_size(n_rows, n_cols))
+
+
+class Context:
+    """One context per (thread, GPU); mirrors edsx_ctx_create/destroy."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.edsx_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise EdsxError(rc, "no usable gfx950 device %d (the engine has no CPU fallback)" % device)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.edsx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EdsxError(rc, self._lib.edsx_last_error(self._h).decode(errors="replace"))
+
+    def _take(self, b):
+        data = ctypes.string_at(b.data, b.size) if b.size else b""
+        self._lib.edsx_buf_free(ctypes.byref(b))
+        return data
+
+    # ---- host-buffer entry points
+    def msa_transform(self, msa, context_len=0):
+        e, s = _Buf(), _Buf()
+        msa = bytes(msa)
+        self._check(self._lib.edsx_msa_transform(self._h, msa, len(msa), context_len,
+                                                 ctypes.byref(e), ctypes.byref(s)))
+        return self._take(e), self._take(s)
+
+    def leds_merge(self, eds, seds=None, context_len=1, compact=True):
+        o, so = _Buf(), _Buf()
+        eds = bytes(eds)
+        sb = bytes(seds) if seds is not None else None
+        self._check(self._lib.edsx_leds_merge(self._h, eds, len(eds), sb, len(sb) if sb is not None else 0,
+                                              context_len, 1 if compact else 0, ctypes.byref(o), ctypes.byref(so)))
+        return self._take(o), self._take(so)
+
+    def vcf_transform(self, vcf, fasta, context_len=0):
+        e, s, st = _Buf(), _Buf(), VcfStats()
+        vcf, fasta = bytes(vcf), bytes(fasta)
+        self._check(self._lib.edsx_vcf_transform(self._h, vcf, len(vcf), fasta, len(fasta), context_len,
+                                                 ctypes.byref(e), ctypes.byref(s), ctypes.byref(st)))
+        return self._take(e), self._take(s), {n: int(getattr(st, n)) for n, _ in VcfStats._fields_}
+
+    # ---- device-resident entry points (pointers are ints: tensor.data_ptr())
+    def msa_plan_device(self, d_msa, n, context_len=0, stream=0):
+        E, Q = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._lib.edsx_msa_plan_device(self._h, d_msa, n, context_len, stream,
+                                                   ctypes.byref(E), ctypes.byref(Q)))
+        return int(E.value), int(Q.value)
+
+    def msa_emit_device(self, d_eds, d_seds, stream=0):
+        self._check(self._lib.edsx_msa_emit_device(self._h, d_eds, d_seds, stream))
+
+    def msa_info(self):
+        info = MsaInfo()
+        rc = self._lib.edsx_msa_last_info(self._h, ctypes.byref(info))
+        if rc != 0:
+            raise EdsxError(rc, "no planned alignment")
+        return {n: int(getattr(info, n)) for n, _ in MsaInfo._fields_}
+
+    def set_timing(self, on):
+        self._lib.edsx_set_timing(self._h, 1 if on else 0)
+
+    def get_timing(self):
+        cap = 64
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = self._lib.edsx_get_timing(self._h, names, ms, cap)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    def msa_synth_device(self, d_out, capacity, n_rows, n_cols, col0=0, variant_fraction=0.05, seed=42,
+                         stream=0):
+        w = ctypes.c_size_t()
+        self._check(self._lib.edsx_msa_synth_device(self._h, d_out, capacity, n_rows, col0, n_cols,
+                                                    variant_fraction, seed, stream, ctypes.byref(w)))
+        return int(w.value)

@@ -1,0 +1,176 @@
+// capi.hip — the extern "C" boundary declared in include/edsx.h.  No exceptions cross it.
+#include "../../include/edsx.h"
+
+#include "msa_device.hpp"
+#include "synth.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace edsx;
+
+struct edsx_ctx {
+    int device = 0;
+    std::string err;
+    MsaPipeline msa;
+    DevBuf d_in, d_eds, d_seds, synth_desc;
+};
+
+namespace {
+
+template <class F> int guarded(edsx_ctx* ctx, F&& f)
+{
+    if (!ctx) return EDSX_ERR_INVALID_PARAMETER;
+    try {
+        ctx->err.clear();
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) throw DeviceError(std::string("hipSetDevice: ") + hipGetErrorString(e));
+        f();
+        return EDSX_OK;
+    } catch (const FormatError& ex) { ctx->err = ex.what(); return EDSX_ERR_INVALID_FORMAT;
+    } catch (const ParamError& ex) { ctx->err = ex.what(); return EDSX_ERR_INVALID_PARAMETER;
+    } catch (const DeviceError& ex) { ctx->err = ex.what(); return EDSX_ERR_BUILD_FAILED;
+    } catch (const std::bad_alloc&) { ctx->err = "out of host memory"; return EDSX_ERR_BUILD_FAILED;
+    } catch (const std::exception& ex) { ctx->err = ex.what(); return EDSX_ERR_UNKNOWN; }
+}
+
+void take(edsx_buf* b, size_t n)
+{
+    b->data = static_cast<uint8_t*>(malloc(n ? n : 1));
+    if (!b->data) throw std::bad_alloc();
+    b->size = n;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* edsx_version(void) { return "edsx 0.1 (gfx950)"; }
+
+int edsx_ctx_create(int device, edsx_ctx** out)
+{
+    if (!out) return EDSX_ERR_INVALID_PARAMETER;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return EDSX_ERR_BUILD_FAILED;           // no GPU: there is no CPU fallback
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return EDSX_ERR_BUILD_FAILED;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return EDSX_ERR_BUILD_FAILED;
+    edsx_ctx* c = new (std::nothrow) edsx_ctx();
+    if (!c) return EDSX_ERR_BUILD_FAILED;
+    c->device = device;
+    *out = c;
+    return EDSX_OK;
+}
+
+void edsx_ctx_destroy(edsx_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    delete ctx;
+}
+
+const char* edsx_last_error(const edsx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void edsx_buf_free(edsx_buf* buf)
+{
+    if (!buf) return;
+    free(buf->data);
+    buf->data = nullptr;
+    buf->size = 0;
+}
+
+int edsx_msa_plan_device(edsx_ctx* ctx, const uint8_t* d_msa, size_t msa_size, uint32_t context_len,
+                         void* stream, uint64_t* eds_bytes, uint64_t* seds_bytes)
+{
+    return guarded(ctx, [&] {
+        if (!d_msa || !eds_bytes || !seds_bytes) throw ParamError("null argument");
+        ctx->msa.plan(d_msa, msa_size, context_len, static_cast<hipStream_t>(stream), eds_bytes, seds_bytes);
+    });
+}
+
+int edsx_msa_emit_device(edsx_ctx* ctx, uint8_t* d_eds, uint8_t* d_seds, void* stream)
+{
+    return guarded(ctx, [&] {
+        if (!d_eds || !d_seds) throw ParamError("null argument");
+        ctx->msa.emit(d_eds, d_seds, static_cast<hipStream_t>(stream));
+    });
+}
+
+int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info)
+{
+    if (!ctx || !info || !ctx->msa.planned()) return EDSX_ERR_INVALID_PARAMETER;
+    const MsaHdr& h = ctx->msa.header();
+    info->n_rows = h.S; info->n_cols = h.L; info->line_width = h.lw ? h.lw : h.L;
+    info->n_variant_cols = h.nv; info->n_segments = h.nseg; info->msa_bytes = ctx->msa.msa_bytes();
+    return EDSX_OK;
+}
+
+void edsx_set_timing(edsx_ctx* ctx, int enabled) { if (ctx) ctx->msa.set_timing(enabled != 0); }
+int edsx_get_timing(const edsx_ctx* ctx, const char** names, float* ms, int cap)
+{
+    return ctx ? ctx->msa.get_timing(names, ms, cap) : 0;
+}
+
+int edsx_msa_transform(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint32_t context_len,
+                       edsx_buf* eds, edsx_buf* seds)
+{
+    if (eds) { eds->data = nullptr; eds->size = 0; }
+    if (seds) { seds->data = nullptr; seds->size = 0; }
+    return guarded(ctx, [&] {
+        if (!msa || !eds || !seds) throw ParamError("null argument");
+        if (msa_size == 0) throw FormatError("Invalid MSA: empty input");
+        hipStream_t st = nullptr;
+        ctx->d_in.ensure(msa_size);
+        EDSX_HIP(hipMemcpyAsync(ctx->d_in.ptr, msa, msa_size, hipMemcpyHostToDevice, st));
+        uint64_t E = 0, Q = 0;
+        ctx->msa.plan(ctx->d_in.as<uint8_t>(), msa_size, context_len, st, &E, &Q);
+        ctx->d_eds.ensure(E + 16);
+        ctx->d_seds.ensure(Q + 16);
+        ctx->msa.emit(ctx->d_eds.as<uint8_t>(), ctx->d_seds.as<uint8_t>(), st);
+        take(eds, E);
+        take(seds, Q);
+        EDSX_HIP(hipMemcpyAsync(eds->data, ctx->d_eds.ptr, E, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipMemcpyAsync(seds->data, ctx->d_seds.ptr, Q, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int edsx_leds_merge(edsx_ctx* ctx, const uint8_t*, size_t, const uint8_t*, size_t, uint32_t, int,
+                    edsx_buf* leds, edsx_buf* seds_out)
+{
+    if (leds) { leds->data = nullptr; leds->size = 0; }
+    if (seds_out) { seds_out->data = nullptr; seds_out->size = 0; }
+    return guarded(ctx, [&] { throw DeviceError("edsx_leds_merge: device path not built yet"); });
+}
+
+int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t*, size_t, const uint8_t*, size_t, uint32_t,
+                       edsx_buf* eds, edsx_buf* seds, edsx_vcf_stats*)
+{
+    if (eds) { eds->data = nullptr; eds->size = 0; }
+    if (seds) { seds->data = nullptr; seds->size = 0; }
+    return guarded(ctx, [&] { throw DeviceError("edsx_vcf_transform: device path not built yet"); });
+}
+
+size_t edsx_msa_synth_size(uint32_t n_rows, uint64_t n_cols) { return synth_size(n_rows, n_cols); }
+
+int edsx_msa_synth_device(edsx_ctx* ctx, uint8_t* d_out, size_t capacity, uint32_t n_rows,
+                          uint64_t col0, uint64_t n_cols, double variant_fraction, uint64_t seed,
+                          void* stream, size_t* written)
+{
+    return guarded(ctx, [&] {
+        if (!d_out || n_rows < 1 || n_cols < 1) throw ParamError("bad synthetic alignment geometry");
+        size_t need = synth_size(n_rows, n_cols);
+        if (capacity < need) throw ParamError("output buffer too small for the synthetic alignment");
+        ctx->synth_desc.ensure(8 * (size_t)n_cols);
+        synth_generate(d_out, ctx->synth_desc.as<u64>(), n_rows, col0, n_cols, variant_fraction, seed,
+                       static_cast<hipStream_t>(stream));
+        EDSX_HIP(hipGetLastError());
+        if (written) *written = need;
+    });
+}
+
+} // extern "C"

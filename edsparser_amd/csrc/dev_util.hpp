@@ -1,0 +1,200 @@
+// dev_util.hpp — small device/host helpers shared by the gfx950 kernels (wave64 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace edsx {
+
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define EDSX_HIP(call)                                                                        \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            throw ::edsx::DeviceError(std::string(#call) + ": " + hipGetErrorString(e__));    \
+    } while (0)
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- wave64 primitives -------------------------------------------------------------------
+__device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ u32 mbcnt(u64 mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
+
+__device__ __forceinline__ u64 mix64(u64 x)
+{   // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ u64 hash3(u64 seed, u64 a, u64 b)
+{
+    return mix64(seed ^ mix64(a ^ mix64(b + 0x632BE59BD9B4E019ull)));
+}
+
+// 16 bytes from an arbitrarily aligned address (gfx950 global loads tolerate misalignment;
+// hipcc emits one global_load_dwordx4 for this)
+struct __attribute__((packed, aligned(1))) U128u { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 load16u(const uint8_t* p)
+{
+    U128u v;
+    __builtin_memcpy(&v, p, 16);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// partial load of n (<16) bytes, zero padded
+__device__ __forceinline__ uint4 load_partial(const uint8_t* p, int n)
+{
+    u64 lo = 0, hi = 0;
+    for (int i = 0; i < n; i++) {
+        u64 b = p[i];
+        if (i < 8) lo |= b << (8 * i);
+        else hi |= b << (8 * (i - 8));
+    }
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+
+// per-byte "a != b" mask of a dword pair as 4 bits
+__device__ __forceinline__ u32 ne_bytes4(uint32_t a, uint32_t b)
+{
+    uint32_t x = a ^ b;
+    // byte != 0  <=>  ((x & 0x7f7f7f7f) + 0x7f7f7f7f | x) & 0x80808080
+    uint32_t t = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+    // gather bits 7,15,23,31 -> 0..3
+    return ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
+}
+__device__ __forceinline__ u32 eq_byte4(uint32_t a, uint32_t cccc) { return 0xFu ^ ne_bytes4(a, cccc); }
+
+__device__ __forceinline__ u32 byte_of(const uint4& v, int i)
+{
+    uint32_t w = (i < 8) ? ((i < 4) ? v.x : v.y) : ((i < 12) ? v.z : v.w);
+    return (w >> ((i & 3) * 8)) & 0xffu;
+}
+
+// decimal digits of v (v >= 1)
+__device__ __forceinline__ u32 ndigits(u32 v)
+{
+    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) +
+           (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+}
+
+// ---- device-wide exclusive scan on u64 arrays, element count read from device memory -------
+// out[i] = sum(in[0..i)), *total = sum of all; in/out may alias.  Three grid-stride kernels.
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;   // 2048
+
+__device__ __forceinline__ u64 block_reduce_sum(u64 v, u64* sh /*[SCAN_THREADS/64]*/)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    u64 t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+static __global__ void k_scan_tile_sums(const u64* __restrict__ in, const u64* __restrict__ n_ptr,
+                                        u64* __restrict__ bsum)
+{
+    __shared__ u64 sh[SCAN_THREADS / 64];
+    const u64 n = *n_ptr;
+    const u64 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        u64 base = t * SCAN_TILE;
+        u64 s = 0;
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            u64 idx = base + (u64)i * SCAN_THREADS + threadIdx.x;
+            if (idx < n) s += in[idx];
+        }
+        s = block_reduce_sum(s, sh);
+        if (threadIdx.x == 0) bsum[t] = s;
+    }
+}
+
+// single workgroup: exclusive scan of bsum[0..ntiles) in place, total -> *total
+static __global__ void k_scan_spine(u64* __restrict__ bsum, const u64* __restrict__ n_ptr,
+                                    u64* __restrict__ total)
+{
+    __shared__ u64 sh[1024];
+    __shared__ u64 carry_sh;
+    const u64 n = *n_ptr;
+    const u64 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    for (u64 base = 0; base < ntiles; base += blockDim.x) {
+        u64 idx = base + threadIdx.x;
+        u64 v = idx < ntiles ? bsum[idx] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < (int)blockDim.x; o <<= 1) {       // Hillis-Steele inclusive
+            u64 a = threadIdx.x >= (u32)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += a;
+            __syncthreads();
+        }
+        u64 incl = sh[threadIdx.x];
+        u64 carry = carry_sh;
+        if (idx < ntiles) bsum[idx] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry_sh = carry + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_sh;
+}
+
+static __global__ void k_scan_apply(const u64* __restrict__ in, u64* __restrict__ out,
+                                    const u64* __restrict__ n_ptr, const u64* __restrict__ bsum)
+{
+    __shared__ u64 wsum[SCAN_THREADS / 64];
+    const u64 n = *n_ptr;
+    const u64 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // blocked arrangement: thread owns SCAN_ITEMS consecutive items
+        u64 base = t * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+        u64 v[SCAN_ITEMS];
+        u64 s = 0;
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            v[i] = (base + i < n) ? in[base + i] : 0;
+            s += v[i];
+        }
+        u64 incl = s;                                           // wave inclusive scan of s
+        for (int o = 1; o < 64; o <<= 1) {
+            u64 a = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += a;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        u64 woff = 0;
+        for (int i = 0; i < w; i++) woff += wsum[i];
+        u64 run = bsum[t] + woff + incl - s;
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            if (base + i < n) out[base + i] = run;
+            run += v[i];
+        }
+        __syncthreads();
+    }
+}
+
+// tmp must hold ceil(capacity / SCAN_TILE) u64
+inline void exclusive_scan_u64(const u64* in, u64* out, const u64* d_n, u64* d_total, u64* tmp,
+                               hipStream_t st)
+{
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1024), dim3(SCAN_THREADS), 0, st, in, d_n, tmp);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, tmp, d_n, d_total);
+    hipLaunchKernelGGL(k_scan_apply, dim3(1024), dim3(SCAN_THREADS), 0, st, in, out, d_n, tmp);
+}
+
+} // namespace edsx

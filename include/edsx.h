@@ -1,0 +1,115 @@
+/*
+ * edsx.h — C ABI of the MI355X-native EDS transformation engine (libedsx.so).
+ *
+ * This is the drop-in boundary for EDSParser's transform hot path.  Every entry point is
+ * `extern "C"`, takes plain pointers and sizes, returns an int status and never throws.
+ * The host-buffer calls are exactly what the reference's Transforms layer would bind (one call
+ * per public function of src/cpp/lib/transforms/): the `edsparser::` C++ shims in
+ * edsparser_amd/host/ slurp the std::istream into a byte buffer and call these.
+ *
+ *   edsx_msa_transform   replaces parse_msa_to_eds_streaming  (msa_transforms.hpp:27,  .cpp:334-345)
+ *                        and      parse_msa_to_leds_streaming (msa_transforms.hpp:37-39, .cpp:351-365)
+ *   edsx_leds_merge      replaces eds_to_leds_linear          (eds_transforms.hpp:29-37, .cpp:313-373)
+ *                        and      eds_to_leds_cartesian       (eds_transforms.hpp:45-51, .cpp:381-426)
+ *   edsx_vcf_transform   replaces parse_vcf_to_eds_streaming  (vcf_transforms.hpp:59-62, .cpp:677-729)
+ *                        and      parse_vcf_to_leds_streaming (vcf_transforms.hpp:75-79, .cpp:735-755)
+ *
+ * Status codes mirror the reference's (unused) ErrorCode enum, src/cpp/lib/common.hpp:37-45.
+ * The *_device calls take HBM pointers on the context's GPU and a hipStream_t (passed as void*),
+ * so pipelines and the benchmark can keep data resident; they are what the host-buffer calls
+ * are built from.  There is NO CPU fallback: every call fails with EDSX_ERR_BUILD_FAILED when no
+ * gfx950 device is usable.
+ */
+#ifndef EDSX_H
+#define EDSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum edsx_status {
+    EDSX_OK = 0,
+    EDSX_ERR_FILE_NOT_FOUND = 1,
+    EDSX_ERR_INVALID_FORMAT = 2,     /* std::runtime_error in the reference (format errors)   */
+    EDSX_ERR_INVALID_PARAMETER = 3,  /* std::invalid_argument / std::out_of_range             */
+    EDSX_ERR_BUILD_FAILED = 4,       /* device / HIP runtime failure, no GPU, out of memory   */
+    EDSX_ERR_QUERY_FAILED = 5,
+    EDSX_ERR_UNKNOWN = 99
+};
+
+typedef struct edsx_ctx edsx_ctx;
+
+/* Host byte buffer allocated by the library; release with edsx_buf_free. */
+typedef struct { uint8_t* data; size_t size; } edsx_buf;
+
+/* Counters of vcf_transforms.hpp:24-35 (VCFStats). */
+typedef struct {
+    uint64_t total_variants, processed_variants, skipped_malformed,
+             skipped_unsupported_sv, variant_groups;
+} edsx_vcf_stats;
+
+/* ---- context: one per (host thread, GPU) ---- */
+int  edsx_ctx_create(int device, edsx_ctx** out);
+void edsx_ctx_destroy(edsx_ctx* ctx);
+/* Message of the last failing call on this context (valid until the next call). */
+const char* edsx_last_error(const edsx_ctx* ctx);
+void edsx_buf_free(edsx_buf* buf);
+const char* edsx_version(void);
+
+/* ---- host-buffer entry points (the drop-in boundary) ---- */
+
+/* MSA (FASTA with '-' gaps) -> EDS (context_len == 0) or l-EDS (context_len > 0) + sEDS.
+ * Output bytes are identical to the std::string pair the reference returns. */
+int edsx_msa_transform(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint32_t context_len,
+                       edsx_buf* eds, edsx_buf* seds);
+
+/* EDS (+ optional sEDS) -> l-EDS.  seds == NULL => CARTESIAN, else LINEAR.
+ * compact != 0 => COMPACT brackets (the CLI default), else FULL.  Outputs end in '\n' like
+ * EDS::save / save_sources; seds_out->size == 0 when no sources were given. */
+int edsx_leds_merge(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size,
+                    const uint8_t* seds, size_t seds_size, uint32_t context_len, int compact,
+                    edsx_buf* leds, edsx_buf* seds_out);
+
+/* VCF + FASTA -> EDS (context_len == 0) or l-EDS (> 0) + sEDS; stats may be NULL. */
+int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size,
+                       const uint8_t* fasta, size_t fasta_size, uint32_t context_len,
+                       edsx_buf* eds, edsx_buf* seds, edsx_vcf_stats* stats);
+
+/* ---- device-resident MSA path (inputs/outputs stay in HBM) ---- */
+
+/* Phase 1: index rows, scan columns, build the segment table and size the outputs.
+ * d_msa must stay valid until the matching edsx_msa_emit_device returns.  Synchronises the
+ * stream once to hand the sizes back. */
+int edsx_msa_plan_device(edsx_ctx* ctx, const uint8_t* d_msa, size_t msa_size, uint32_t context_len,
+                         void* stream, uint64_t* eds_bytes, uint64_t* seds_bytes);
+/* Phase 2: write the .eds / .seds text into caller-provided HBM buffers of at least the planned
+ * sizes.  Asynchronous on `stream`. */
+int edsx_msa_emit_device(edsx_ctx* ctx, uint8_t* d_eds, uint8_t* d_seds, void* stream);
+
+/* Geometry of the last planned alignment (for reporting). */
+typedef struct {
+    uint64_t n_rows, n_cols, line_width, n_variant_cols, n_segments, msa_bytes;
+} edsx_msa_info;
+int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info);
+
+/* Per-kernel device time of the last plan+emit, measured with HIP events on the call's stream.
+ * names/ms arrays of capacity cap; returns the number of entries. Enabled by edsx_set_timing. */
+void edsx_set_timing(edsx_ctx* ctx, int enabled);
+int  edsx_get_timing(const edsx_ctx* ctx, const char** names, float* ms, int cap);
+
+/* ---- synthetic genrandomeds-shaped alignment, generated in HBM (bench / tests) ----
+ * Rows 0..n_rows-1 of alignment columns [col0, col0+n_cols) of a virtual alignment, one line per
+ * row, headers ">s<row>", trailing newline.  Bytes depend only on (seed, global column, row), so a
+ * column slab generated on another GPU is bit-identical to the same columns of the whole. */
+size_t edsx_msa_synth_size(uint32_t n_rows, uint64_t n_cols);
+int edsx_msa_synth_device(edsx_ctx* ctx, uint8_t* d_out, size_t capacity, uint32_t n_rows,
+                          uint64_t col0, uint64_t n_cols, double variant_fraction, uint64_t seed,
+                          void* stream, size_t* written);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDSX_H */

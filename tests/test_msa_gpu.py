@@ -1,0 +1,107 @@
+"""GPU parity tests for the MSA -> EDS / l-EDS path: the HIP pipeline, called through the C ABI
+(edsx_msa_transform / edsx_msa_plan_device + edsx_msa_emit_device), must be byte-identical to
+the CPU oracle and to the reference's golden vectors."""
+import json
+import os
+import random
+
+import pytest
+
+import oracle_lib as o
+from conftest import GOLDEN
+from msa_cases import random_msa
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import edsparser_amd
+    c = edsparser_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _kat():
+    return json.load(open(os.path.join(GOLDEN, "kat_msa.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", _kat(), ids=lambda c: c["name"])
+def test_reference_vectors(ctx, case):
+    msa = case["msa"].encode() if "msa" in case else open(os.path.join(GOLDEN, case["msa_file"]), "rb").read()
+    eds, seds = ctx.msa_transform(msa, case["l"])
+    assert eds.decode() == case["eds"]
+    assert seds.decode() == case["seds"]
+
+
+@pytest.mark.parametrize("l", [0, 1, 2, 3, 5, 8, 32])
+def test_random_small_alignments(ctx, l):
+    rng = random.Random(1000 + l)
+    for i in range(60):
+        msa = random_msa(rng, trailing_newline=(i % 3 != 0))
+        want = o.msa(msa, l)
+        got = ctx.msa_transform(msa, l)
+        assert got == want, (l, i, msa)
+
+
+def test_many_rows_and_wide_rows(ctx):
+    rng = random.Random(7)
+    for S, L, lw in [(100, 300, None), (1000, 70, 70), (1030, 40, 40), (2, 5000, 5000), (300, 1000, 60),
+                     (4097, 33, 33), (5000, 20, 20)]:
+        msa = random_msa(rng, S=S, L=L, lw=lw)
+        for l in (0, 4):
+            assert ctx.msa_transform(msa, l) == o.msa(msa, l), (S, L, lw, l)
+
+
+def test_format_errors(ctx):
+    import edsparser_amd
+    for bad in [b"", b"ACGT\n", b">a\nACGT\n", b">a\nACGT\n>b\nAC\n", b">a\nACGT\n>b\nACGTA\n",
+                b">a\nAC\nGT\n>b\nACG\nT\n"]:
+        with pytest.raises(edsparser_amd.EdsxError) as ei:
+            ctx.msa_transform(bad, 0)
+        assert ei.value.code == 2, bad
+
+
+def test_trailing_blank_lines_tolerated(ctx):
+    msa = b">a\nACGT\n>b\nACGA\n\n\n"
+    assert ctx.msa_transform(msa, 0) == o.msa(msa, 0)
+
+
+@pytest.mark.parametrize("S,L,l", [(48, 20000, 0), (48, 20000, 10), (64, 200000, 0), (1000, 30000, 0),
+                                    (1000, 30000, 6), (7, 100003, 0)])
+def test_synthetic_device_path(ctx, S, L, l):
+    """genrandomeds-shaped alignment generated in HBM, device-resident plan/emit vs the oracle."""
+    import torch
+    import edsparser_amd
+    n = edsparser_amd.synth_size(S, L)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_synth_device(buf.data_ptr(), n, S, L, seed=42 + S)
+    E, Q = ctx.msa_plan_device(buf.data_ptr(), n, l)
+    d_eds = torch.empty(E + 16, dtype=torch.uint8, device="cuda:0")
+    d_seds = torch.empty(Q + 16, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_emit_device(d_eds.data_ptr(), d_seds.data_ptr())
+    torch.cuda.synchronize()
+    host = bytes(buf.cpu().numpy())
+    assert host.count(b">") == S
+    oe, os_ = o.msa(host, l)
+    assert bytes(d_eds[:E].cpu().numpy()) == oe
+    assert bytes(d_seds[:Q].cpu().numpy()) == os_
+    info = ctx.msa_info()
+    assert info["n_rows"] == S and info["n_cols"] == L
+
+
+def test_synthetic_slabs_match_whole(ctx):
+    """Column slabs generated separately are the same bytes as the columns of the whole."""
+    import torch
+    import edsparser_amd
+    S, L = 9, 4000
+    n = edsparser_amd.synth_size(S, L)
+    whole = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_synth_device(whole.data_ptr(), n, S, L, seed=5)
+    rows = [r.split(b"\n")[1] for r in bytes(whole.cpu().numpy()).split(b">")[1:]]
+    for c0, c1 in [(0, 1000), (1000, 2500), (2500, 4000)]:
+        m = edsparser_amd.synth_size(S, c1 - c0)
+        part = torch.empty(m, dtype=torch.uint8, device="cuda:0")
+        ctx.msa_synth_device(part.data_ptr(), m, S, c1 - c0, col0=c0, seed=5)
+        prow = [r.split(b"\n")[1] for r in bytes(part.cpu().numpy()).split(b">")[1:]]
+        assert prow == [r[c0:c1] for r in rows]
