@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — MSA -> EDS input MB/s on MI355X (BASELINE.json metric), with the HBM roofline of the
+dominant kernel and a CPU baseline timed in the same run.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path (edsx_msa_plan_device + edsx_msa_emit_device: row index,
+column scan + variant-column extraction, segment table, per-segment grouping, scans, .eds/.seds
+text) over one synthetic alignment that is already resident in HBM.  Workload at N=1: BASELINE
+configs[4], 1000 sequences x 100 Mb (genrandomeds-shaped, 5 % variant sites, one line per row).
+With N ranks the alignment is N x 100 Mb columns, range-partitioned by columns (weak scaling):
+every rank transforms its own slab and the boundary segments are stitched over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md "HBM3E peak BW")
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=1000)
+    ap.add_argument("--cols", type=int, default=100_000_000, help="alignment columns per GPU")
+    ap.add_argument("--context-len", type=int, default=0)
+    ap.add_argument("--variant-fraction", type=float, default=0.05)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--cpu-baseline-mb", type=float, default=3000.0,
+                    help="size of the CPU-baseline sample in MB (0 = skip)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
+    return ap.parse_args()
+
+
+def cpu_baseline(ctx, torch, rows, sample_mb, vfrac, seed, l):
+    """The oracle ("port" of the reference's 3-pass algorithm) on one host core, bounded sample of
+    the same workload shape (same rows, fewer columns)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import edsparser_amd
+    cols = max(1000, int(sample_mb * 1e6 / (rows + 1)))
+    n = edsparser_amd.synth_size(rows, cols)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ctx.msa_synth_device(buf.data_ptr(), n, rows, cols, variant_fraction=vfrac, seed=seed)
+    torch.cuda.synchronize()
+    host = bytes(buf.cpu().numpy())
+    del buf
+    t0 = time.perf_counter()
+    e, s = oracle_lib.msa(host, l)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "%d rows x %d columns (%.0f MB in, %.1f s), same generator and site fraction"
+                      % (rows, cols, n / 1e6, dt)}
+
+
+def main():
+    a = parse_args()
+    import torch
+    import torch.distributed as dist
+    import edsparser_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (a.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = edsparser_amd.Context(local_rank)
+    S, L, l = a.rows, a.cols, a.context_len
+    n = edsparser_amd.synth_size(S, L)
+    msa = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ctx.msa_synth_device(msa.data_ptr(), n, S, L, col0=rank * L, variant_fraction=a.variant_fraction,
+                         seed=a.seed)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    stitcher = None
+    if world > 1:
+        from edsparser_amd.multigpu import SlabStitcher
+        stitcher = SlabStitcher(ctx, rank, world, S)
+
+    out = {"eds": None, "seds": None, "E": 0, "Q": 0}
+
+    def step():
+        E, Q = ctx.msa_plan_device(msa.data_ptr(), n, l, stream)
+        if out["eds"] is None or out["eds"].numel() < E + 16:
+            out["eds"] = torch.empty(E + 16, dtype=torch.uint8, device="cuda")
+        if out["seds"] is None or out["seds"].numel() < Q + 16:
+            out["seds"] = torch.empty(Q + 16, dtype=torch.uint8, device="cuda")
+        ctx.msa_emit_device(out["eds"].data_ptr(), out["seds"].data_ptr(), stream)
+        out["E"], out["Q"] = E, Q
+        if stitcher is not None:
+            stitcher.stitch(msa, n, L, out)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.set_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timing = ctx.get_timing()
+    ctx.set_timing(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    info = ctx.msa_info()
+    if rank == 0:
+        total_in = float(n) * world * a.steps
+        value = total_in / dt / 1e6
+        dom = max(timing, key=lambda t: t[1]) if timing else None
+        roof = None
+        per_kernel = {}
+        for name, tot, cnt in timing:
+            per_kernel[name] = round(tot / max(cnt, 1), 4)
+        if dom:
+            name, tot, cnt = dom
+            avg_ms = tot / cnt
+            if name == "k_scan_extract":
+                alg = float(S) * float(L)     # 1 B read per alignment cell
+                what = "S*L alignment cells read once"
+            elif name in ("k_emit_variant", "k_seg_count"):
+                alg = float(info["n_variant_cols"]) * S + (out["Q"] if name == "k_emit_variant" else 0)
+                what = "variant-column bytes read" + (" + .seds bytes written" if name == "k_emit_variant" else "")
+            else:
+                alg = float(n)
+                what = "input bytes"
+            ach = alg / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": a.traffic_bytes, "avg_kernel_ms": round(avg_ms, 4),
+                    "algorithmic_bytes_per_launch": alg, "algorithmic_bytes": what}
+        cpu = None
+        if world == 1 and a.cpu_baseline_mb > 0:
+            cpu = cpu_baseline(ctx, torch, S, a.cpu_baseline_mb, a.variant_fraction, a.seed, l)
+        line = {
+            "metric": "msa2eds_input_MB_per_s", "value": round(value, 1), "unit": "MB/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "msa2eds %d-seq x %d-column synthetic alignment per GPU "
+                                   "(genrandomeds-shaped, %.0f%% sites, one line per row)"
+                                   % (S, L, a.variant_fraction * 100),
+                       "rows": S, "cols_per_gpu": L, "context_len": l,
+                       "input_bytes_per_gpu": n, "eds_bytes": out["E"], "seds_bytes": out["Q"],
+                       "partition": "columns x %d" % world},
+            "frac_of_hbm_read_roofline": round(value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4),
+            "roofline": roof, "cpu_baseline": cpu, "kernel_ms": per_kernel,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,7 +66,8 @@ def load_library():
     lib.edsx_msa_emit_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.edsx_msa_last_info.argtypes = [ctypes.c_void_p, P(MsaInfo)]
     lib.edsx_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    lib.edsx_get_timing.argtypes = [ctypes.c_void_p, P(ctypes.c_char_p), P(ctypes.c_float), ctypes.c_int]
+    lib.edsx_get_timing.argtypes = [ctypes.c_void_p, P(ctypes.c_char_p), P(ctypes.c_float), P(ctypes.c_int),
+                                    ctypes.c_int]
     lib.edsx_msa_synth_size.argtypes = [ctypes.c_uint32, ctypes.c_uint64]
     lib.edsx_msa_synth_size.restype = ctypes.c_size_t
     lib.edsx_msa_synth_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
@@ -159,8 +160,9 @@ class Context:
         cap = 64
         names = (ctypes.c_char_p * cap)()
         ms = (ctypes.c_float * cap)()
-        n = self._lib.edsx_get_timing(self._h, names, ms, cap)
-        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+        cnt = (ctypes.c_int * cap)()
+        n = self._lib.edsx_get_timing(self._h, names, ms, cnt, cap)
+        return [(names[i].decode(), float(ms[i]), int(cnt[i])) for i in range(n)]
 
     def msa_synth_device(self, d_out, capacity, n_rows, n_cols, col0=0, variant_fraction=0.05, seed=42,
                          stream=0):

@@ -110,9 +110,9 @@ int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info)
 }
 
 void edsx_set_timing(edsx_ctx* ctx, int enabled) { if (ctx) ctx->msa.set_timing(enabled != 0); }
-int edsx_get_timing(const edsx_ctx* ctx, const char** names, float* ms, int cap)
+int edsx_get_timing(edsx_ctx* ctx, const char** names, float* total_ms, int* launches, int cap)
 {
-    return ctx ? ctx->msa.get_timing(names, ms, cap) : 0;
+    return ctx ? ctx->msa.get_timing(names, total_ms, launches, cap) : 0;
 }
 
 int edsx_msa_transform(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint32_t context_len,

@@ -746,19 +746,35 @@ void MsaPipeline::launch_timer_end(hipStream_t st)
     if (!timing_) return;
     EDSX_HIP(hipEventRecord(timed_.back().t1, st));
 }
+// harvest the finished event pairs of the previous call into the per-kernel accumulators
 void MsaPipeline::clear_timers()
 {
-    for (auto& t : timed_) { (void)hipEventDestroy(t.t0); (void)hipEventDestroy(t.t1); }
+    if (!timed_.empty()) (void)hipEventSynchronize(timed_.back().t1);
+    for (auto& t : timed_) {
+        float v = 0;
+        if (hipEventElapsedTime(&v, t.t0, t.t1) == hipSuccess) {
+            bool found = false;
+            for (auto& a : acc_) if (a.name == t.name) { a.total_ms += v; a.count++; found = true; break; }
+            if (!found) acc_.push_back({t.name, v, 1});
+        }
+        (void)hipEventDestroy(t.t0); (void)hipEventDestroy(t.t1);
+    }
     timed_.clear();
 }
-int MsaPipeline::get_timing(const char** names, float* ms, int cap) const
+void MsaPipeline::set_timing(bool on)
 {
+    clear_timers();
+    acc_.clear();
+    timing_ = on;
+}
+// accumulated device time per kernel since set_timing(true): ms[i] = total, counts[i] = launches
+int MsaPipeline::get_timing(const char** names, float* ms, int* counts, int cap)
+{
+    clear_timers();
     int n = 0;
-    for (const auto& t : timed_) {
+    for (const auto& a : acc_) {
         if (n >= cap) break;
-        float v = 0;
-        if (hipEventElapsedTime(&v, t.t0, t.t1) != hipSuccess) v = -1.f;
-        names[n] = t.name; ms[n] = v; n++;
+        names[n] = a.name; ms[n] = (float)a.total_ms; counts[n] = a.count; n++;
     }
     return n;
 }

@@ -69,11 +69,13 @@ public:
     bool planned() const { return planned_; }
     size_t msa_bytes() const { return n_; }
 
-    void set_timing(bool on) { timing_ = on; }
-    int get_timing(const char** names, float* ms, int cap) const;
+    void set_timing(bool on);
+    int get_timing(const char** names, float* ms, int* counts, int cap);
 
 private:
     struct TimedKernel { const char* name; hipEvent_t t0, t1; };
+    struct TimeAcc { const char* name; double total_ms; int count; };
+    std::vector<TimeAcc> acc_;
     void launch_timer_begin(const char* name, hipStream_t st);
     void launch_timer_end(hipStream_t st);
     void clear_timers();

@@ -95,10 +95,11 @@ typedef struct {
 } edsx_msa_info;
 int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info);
 
-/* Per-kernel device time of the last plan+emit, measured with HIP events on the call's stream.
- * names/ms arrays of capacity cap; returns the number of entries. Enabled by edsx_set_timing. */
+/* Per-kernel device time, measured with HIP events on the stream each kernel is launched on and
+ * accumulated over all plan/emit calls since edsx_set_timing(ctx, 1).  Arrays of capacity cap;
+ * total_ms[i] / launches[i] is the average duration of kernel names[i].  Returns the entry count. */
 void edsx_set_timing(edsx_ctx* ctx, int enabled);
-int  edsx_get_timing(const edsx_ctx* ctx, const char** names, float* ms, int cap);
+int  edsx_get_timing(edsx_ctx* ctx, const char** names, float* total_ms, int* launches, int cap);
 
 /* ---- synthetic genrandomeds-shaped alignment, generated in HBM (bench / tests) ----
  * Rows 0..n_rows-1 of alignment columns [col0, col0+n_cols) of a virtual alignment, one line per
