@@ -167,6 +167,8 @@ def main():
                                    % (S, L, a.variant_fraction * 100),
                        "rows": S, "cols_per_gpu": L, "context_len": l,
                        "input_bytes_per_gpu": n, "eds_bytes": out["E"], "seds_bytes": out["Q"],
+                       "segments": info["n_segments"], "variant_cols": info["n_variant_cols"],
+                       "slow_segments": info["n_slow_segments"],
                        "partition": "columns x %d" % world},
             "frac_of_hbm_read_roofline": round(value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4),
             "roofline": roof, "cpu_baseline": cpu, "kernel_ms": per_kernel,

@@ -28,11 +28,12 @@ class VcfStats(ctypes.Structure):
 
 class MsaInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in
-                ("n_rows", "n_cols", "line_width", "n_variant_cols", "n_segments", "msa_bytes")]
+                ("n_rows", "n_cols", "line_width", "n_variant_cols", "n_segments", "msa_bytes",
+                 "n_slow_segments")]
 
 
 def lib_path():
-    return os.path.join(_HERE, "libedsx.so")
+    return os.environ.get("EDSX_LIB") or os.path.join(_HERE, "libedsx.so")
 
 
 def load_library():

@@ -12,7 +12,8 @@
 //                 rows (msa_transforms.cpp:268-269) and c for one-line rows.
 //   Vraw / V      1 bit per raw position / alignment column: 1 = variant column (some row differs
 //                 from row 0, or row 0 has '-').  Complement of the reference's bit-vector B.
-//   vc            the variant columns only, column-major: vc[slot * Spad + r] = byte of row r.
+//   vc            the variant columns only, column-major: vc[slot * Spad + vc_pos(r)] = byte of row r
+//                 (rows permuted so that a lane's 16-byte load holds rows lane, lane+64, ...).
 //                 Slots are handed out per tile by an atomic counter (unordered between tiles,
 //                 consecutive inside a 64-column word); word_slot[w] = slot of the first variant
 //                 column of raw word w.  Every later kernel reads rows through vc, so the S x L
@@ -23,6 +24,7 @@
 #include "msa_device.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 
 namespace edsx {
@@ -34,6 +36,14 @@ enum : u64 {
     ST_NOT_FASTA = 1, ST_LAYOUT = 2, ST_TOO_MANY_ROWS = 4, ST_VC_OVERFLOW = 8,
     ST_NEWLINE_IN_DATA = 16, ST_FEW_ROWS = 32
 };
+
+// tell the compiler a value is wave-uniform (it then lives in SGPRs and branches on it are scalar)
+__device__ __forceinline__ u64 uniform64(u64 v)
+{
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) |
+           (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
+__device__ __forceinline__ u32 uniform32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 
 __device__ __forceinline__ u64 ld_relaxed(const u64* p)
 {
@@ -157,7 +167,7 @@ __global__ void k_index_rows(const uint8_t* __restrict__ f, u64 n, MsaHdr* h,
 struct K1Params {
     const uint8_t* file; const u64* row_start; MsaHdr* hdr;
     u64* Vraw; u64* word_slot; uint8_t* vc; u64 vc_cap_cols;
-    u64 Draw, lw; u32 S, Spad, cpr_log2, cap_cols /* LDS colbuf capacity in columns */;
+    u64 Draw, lw; u32 S, Spad, Gp, cpr_log2, cap_cols /* LDS colbuf capacity in columns */;
     u64 ntiles;
 };
 
@@ -179,7 +189,7 @@ template <int I> __device__ __forceinline__ u32 byte_at(const uint4& v)
     return (w >> ((I & 3) * 8)) & 0xffu;
 }
 
-template <int T, int RPT, bool HOLD>
+template <int T, int RPT, bool HOLD, bool LANEROWS>
 __global__ void __launch_bounds__(T) k_scan_extract(K1Params p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t colbuf[];
@@ -221,19 +231,22 @@ __global__ void __launch_bounds__(T) k_scan_extract(K1Params p)
     uint4 ref = make_uint4(0, 0, 0, 0);
     uint4 d[HOLD ? RPT : 1];
     uint4 acc = make_uint4(0, 0, 0, 0);                        // OR over rows of (row ^ ref): a byte is
-    if (full_tile) {                                           // non-zero iff some row differs there                                           // fast path: unconditional 16-B loads
-        ref = load16u(f + rs[0] + q);
-        uint4 v[RPT];
+    if (full_tile) {                                           // non-zero iff some row differs there
+        ref = load16u(f + rs[0] + q);                          // fast path: unconditional 16-B loads
 #pragma unroll
         for (int it = 0; it < RPT; it++) {
             const u32 r = sub + it * RI;
-            v[it] = load16u(f + rs[r < p.S ? r : Sm1] + q);    // clamped: rows past S re-read row S-1
+            d[HOLD ? it : 0] = load16u(f + rs[r < p.S ? r : Sm1] + q);   // clamped: rows past S re-read row S-1
+            if constexpr (!HOLD) {
+                acc.x |= d[0].x ^ ref.x; acc.y |= d[0].y ^ ref.y; acc.z |= d[0].z ^ ref.z; acc.w |= d[0].w ^ ref.w;
+            }
         }
+        if constexpr (HOLD) {
 #pragma unroll
-        for (int it = 0; it < RPT; it++) {
-            if constexpr (HOLD) d[it] = v[it];
-            acc.x |= v[it].x ^ ref.x; acc.y |= v[it].y ^ ref.y;   // a clamped duplicate changes nothing
-            acc.z |= v[it].z ^ ref.z; acc.w |= v[it].w ^ ref.w;
+            for (int it = 0; it < RPT; it++) {                 // a clamped duplicate changes nothing
+                acc.x |= d[it].x ^ ref.x; acc.y |= d[it].y ^ ref.y;
+                acc.z |= d[it].z ^ ref.z; acc.w |= d[it].w ^ ref.w;
+            }
         }
     } else {
         if (nb > 0) ref = load_partial(f + rs[0] + q, nb);
@@ -242,7 +255,7 @@ __global__ void __launch_bounds__(T) k_scan_extract(K1Params p)
             const u32 r = sub + it * RI;
             uint4 v = ref;
             if (r < p.S && nb > 0) v = load_partial(f + rs[r] + q, nb);
-            if constexpr (HOLD) d[it] = v;
+            d[HOLD ? it : 0] = v;
             acc.x |= v.x ^ ref.x; acc.y |= v.y ^ ref.y; acc.z |= v.z ^ ref.z; acc.w |= v.w ^ ref.w;
         }
     }
@@ -318,12 +331,20 @@ __global__ void __launch_bounds__(T) k_scan_extract(K1Params p)
                     if (V16 & (1u << I)) {                                                     \
                         if (idx >= b0 && idx < b0 + cap) {                                     \
                             uint8_t* dst = colbuf + (size_t)(idx - b0) * p.Spad;               \
-                            _Pragma("unroll") for (int it = 0; it < RPT; it++) {               \
-                                const u32 r = sub + it * RI;                                   \
-                                if (r < p.S) {                                                 \
-                                    const u32 ch = byte_at<I>(d[it]);                          \
-                                    if (ch == '\n') bad = 1;                                   \
-                                    dst[r] = (uint8_t)ch;                                      \
+                            if constexpr (LANEROWS) { /* RI == 64, Gp == 16: this thread's 16 rows are 16 */ \
+                                uint32_t w[4];  /* consecutive bytes of the permuted column      */ \
+                                _Pragma("unroll") for (int k4 = 0; k4 < 4; k4++)               \
+                                    w[k4] = byte_at<I>(d[4 * k4]) | (byte_at<I>(d[4 * k4 + 1]) << 8) | \
+                                            (byte_at<I>(d[4 * k4 + 2]) << 16) | (byte_at<I>(d[4 * k4 + 3]) << 24); \
+                                *reinterpret_cast<uint4*>(dst + sub * 16) = make_uint4(w[0], w[1], w[2], w[3]); \
+                            } else {                                                           \
+                                _Pragma("unroll") for (int it = 0; it < RPT; it++) {           \
+                                    const u32 r = sub + it * RI;                               \
+                                    if (r < p.S) {                                             \
+                                        const u32 ch = byte_at<I>(d[it]);                      \
+                                        if (ch == '\n') bad = 1;                               \
+                                        dst[vc_pos(r, p.Gp)] = (uint8_t)ch;                    \
+                                    }                                                          \
                                 }                                                              \
                             }                                                                  \
                         }                                                                      \
@@ -342,7 +363,7 @@ __global__ void __launch_bounds__(T) k_scan_extract(K1Params p)
                             for (u32 r = sub; r < p.S; r += RI) {
                                 u32 ch = f[p.row_start[r] + q + i];
                                 if (ch == '\n') bad = 1;
-                                dst[r] = (uint8_t)ch;
+                                dst[vc_pos(r, p.Gp)] = (uint8_t)ch;
                             }
                         }
                         idx++;
@@ -470,12 +491,12 @@ struct SegLds {
 
 __device__ __forceinline__ u32 seg_col_byte(const MsaView& mv, u64 c, u32 r, u32 isvar, u64 slot)
 {
-    return isvar ? mv.vc[slot * mv.Spad + r] : mv.ref_byte(c);
+    return isvar ? mv.vc[slot * mv.Spad + vc_pos(r, mv.Gp)] : mv.ref_byte(c);
 }
 
 // gap-stripped string of row r over [a,b): the reference drops '\n' and '-' and stops at '\0'
 // (msa_transforms.cpp:281-286)
-__device__ u64 seg_row_key(const MsaView& mv, u64 a, u64 b, u32 r, bool exact)
+__device__ u64 seg_row_key(const MsaView& mv, u64 a, u64 b, u32 r, bool exact, u32& saw_nl)
 {
     u64 key = exact ? 0ull : 0xcbf29ce484222325ull;
     u32 len = 0;
@@ -484,6 +505,7 @@ __device__ u64 seg_row_key(const MsaView& mv, u64 a, u64 b, u32 r, bool exact)
         u64 sl = isvar ? mv.slot(c) : 0;
         u32 ch = seg_col_byte(mv, c, r, isvar, sl);
         if (ch == 0) break;
+        if (ch == '\n') saw_nl = 1;
         if (ch == '-' || ch == '\n') continue;
         if (exact) key |= (u64)ch << (8 * len);
         else key = (key ^ ch) * 0x100000001b3ull;
@@ -529,15 +551,95 @@ __device__ u32 seg_row_len(const MsaView& mv, u64 a, u64 b, u32 r)
     return len;
 }
 
+// hash-table grouping (S <= HT_MAX_ROWS): every row inserts its key into an LDS open-addressing
+// table and takes atomicMin(row) on its slot, so each group learns its first row in O(1) rounds
+// (the iterative path below needs one barrier round per distinct string).  Hashed keys are verified
+// byte for byte against the group's first row; a collision falls back to the iterative path.
+constexpr u32 HT_MAX_ROWS = 2048, HT_SIZE = 4096;
+constexpr u64 HT_EMPTY = ~0ull;
+struct HtLds {
+    u64* tabk; u32* tabm; u32* bm; u32* pre; u32* flag;
+    __device__ HtLds(uint8_t* base)
+    {
+        tabk = reinterpret_cast<u64*>(base);
+        tabm = reinterpret_cast<u32*>(base + (size_t)8 * HT_SIZE);
+        bm = reinterpret_cast<u32*>(base + (size_t)12 * HT_SIZE);
+        pre = bm + 72;
+        flag = pre + 72;
+    }
+    static constexpr size_t BYTES = (size_t)12 * HT_SIZE + 4 * (72 + 72 + 8);
+};
+
 // returns k (number of distinct strings); fills lds.gid[], lds.rep_row[0..k)
 __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* rep_sh)
 {
     const u32 S = mv.S;
     const bool exact = (b - a) <= 8;
+    u32 saw_nl = 0;
     for (u32 r = threadIdx.x; r < S; r += GT) {
-        lds.key[r] = seg_row_key(mv, a, b, r, exact);
+        lds.key[r] = seg_row_key(mv, a, b, r, exact, saw_nl);
         lds.gid[r] = GID_NONE;
     }
+    if (saw_nl) atomicOr(&mv.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));   // a row is ragged
+
+    if (S <= HT_MAX_ROWS) {
+        HtLds ht(reinterpret_cast<uint8_t*>(lds.gid + ((S + 7) & ~7u)));
+        for (u32 i = threadIdx.x; i < HT_SIZE; i += GT) { ht.tabk[i] = HT_EMPTY; ht.tabm[i] = 0xffffffffu; }
+        for (u32 i = threadIdx.x; i < 72; i += GT) ht.bm[i] = 0;
+        if (threadIdx.x == 0) *ht.flag = 0;
+        __syncthreads();
+        for (u32 r = threadIdx.x; r < S; r += GT) {
+            u64 kk = lds.key[r];
+            if (kk == HT_EMPTY) kk = HT_EMPTY - 1;
+            u32 slot = (u32)(mix64(kk) >> 20) & (HT_SIZE - 1);
+            while (true) {
+                const u64 cur = atomicCAS(&ht.tabk[slot], HT_EMPTY, kk);
+                if (cur == HT_EMPTY || cur == kk) { atomicMin(&ht.tabm[slot], r); lds.run[r] = slot; break; }
+                slot = (slot + 1) & (HT_SIZE - 1);
+            }
+        }
+        __syncthreads();
+        for (u32 r = threadIdx.x; r < S; r += GT) {
+            const u32 f = ht.tabm[lds.run[r]];
+            if (!exact && f != r && !seg_rows_equal(mv, a, b, r, f)) *ht.flag = 1;
+            lds.rep_row[r] = f;                       // temporarily: first row of r's group
+            if (f == r) atomicOr(&ht.bm[r >> 5], 1u << (r & 31));
+        }
+        __syncthreads();
+        if (*ht.flag == 0) {
+            const u32 nwords = (S + 31) >> 5;
+            if (threadIdx.x < nwords) {
+                u32 acc = 0;
+                for (u32 w = 0; w < threadIdx.x; w++) acc += __builtin_popcount(ht.bm[w]);
+                ht.pre[threadIdx.x] = acc;
+            }
+            if (threadIdx.x == 0) {
+                u32 acc = 0;
+                for (u32 w = 0; w < nwords; w++) acc += __builtin_popcount(ht.bm[w]);
+                *rep_sh = acc;
+            }
+            __syncthreads();
+            u32 myg[HT_MAX_ROWS / GT];
+            for (u32 j = 0, r = threadIdx.x; r < S; r += GT, j++) {
+                const u32 f = lds.rep_row[r];
+                myg[j] = ht.pre[f >> 5] + __builtin_popcount(ht.bm[f >> 5] & ((1u << (f & 31)) - 1u));
+            }
+            __syncthreads();                              // rep_row[] is rewritten below
+            for (u32 j = 0, r = threadIdx.x; r < S; r += GT, j++) {
+                const u32 f = lds.rep_row[r];
+                lds.gid[r] = (uint16_t)myg[j];
+                (void)f;
+            }
+            __syncthreads();
+            for (u32 j = 0, r = threadIdx.x; r < S; r += GT, j++)
+                if (ht.tabm[lds.run[r]] == r) lds.rep_row[myg[j]] = r;
+            const u32 k = *rep_sh;
+            __syncthreads();
+            return k;
+        }
+        __syncthreads();                                  // hash collision: redo iteratively
+    }
+
     u32 g = 0;
     u32 cursor = threadIdx.x;                       // first possibly unassigned row of this thread
     while (true) {
@@ -563,6 +665,7 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
 
 struct SegParams {
     MsaView mv; const u64* seg_start; const u64* nseg_ptr; u64* eds_len; u64* seds_len; u64 tok_total;
+    const u64* list; const u64* list_n;       // when set: only these segments (left over by the fast path)
 };
 
 // K3: per-segment output sizes.  common: "{" ref "}" and "{0}"; variant: see generate_output.
@@ -573,8 +676,9 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
     __shared__ u64 sum_sh;
     SegLds lds(lds_raw, p.mv.S);
     if (p.mv.hdr->status) return;                     // vc overflow: the host grows vc and replans
-    const u64 nseg = *p.nseg_ptr;
-    for (u64 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const u64 nitems = p.list ? *p.list_n : *p.nseg_ptr;
+    for (u64 it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const u64 seg = p.list ? p.list[it] : it;
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         if (!p.mv.vbit(a)) {
             if (threadIdx.x == 0) { p.eds_len[seg] = 2 + (b - a); p.seds_len[seg] = 3; }
@@ -601,6 +705,7 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
 struct EmitParams {
     MsaView mv; const u64* seg_start; const u64* nseg_ptr; const u64* Hseg; const u64* segbase;
     const u64* eds_off; const u64* seds_off; uint8_t* eds; uint8_t* seds; u64 nwords;
+    const u64* list; const u64* list_n;
 };
 
 __global__ void __launch_bounds__(256) k_emit_common(EmitParams p)
@@ -644,9 +749,10 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
     const u32 S = mv.S;
     SegLds lds(lds_raw, S);
     if (mv.hdr->status) return;
-    const u64 nseg = *p.nseg_ptr;
+    const u64 nitems = p.list ? *p.list_n : *p.nseg_ptr;
     const u32 lane = threadIdx.x & 63;
-    for (u64 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    for (u64 it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const u64 seg = p.list ? p.list[it] : it;
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         if (!mv.vbit(a)) continue;
         const u32 k = group_segment(mv, a, b, lds, &rep_sh);
@@ -724,6 +830,587 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fast path (S <= 1024): one WAVE per variant segment, rows in registers.
+//   lane holds rows lane, lane+64, ... (byte i of its 16-byte vc load = row i*64+lane), so row
+//   order = (i, lane) and consecutive ids sit in consecutive lanes.  Per-row state is SWAR bytes
+//   in a uint4: gid (group id), rm (rows not yet grouped).
+//   Grouping: rows are first grouped by RAW equality over the segment's columns ('-' and '\n'
+//   normalised to 0), which needs no per-row gap stripping; the gap-stripped string of each group
+//   is then built once, in scalar registers, from its representative.  Two raw groups with the
+//   same stripped string (same letters, different gap placement), more than KMAX groups or more
+//   than 16 columns send the segment to the generic workgroup-per-segment kernels (slow_list).
+// ---------------------------------------------------------------------------------------------
+constexpr int KMAX = 8;
+constexpr u64 META_FAST = 1ull << 63;     // | ncol << 48 | slot of the first column
+constexpr u64 META_SCATTER = 1ull << 61;  // slots of the columns are not consecutive (tile edge)
+constexpr u64 META_SLOT = 0xffffffffffffull;
+
+// thread per segment: sizes of common segments, slot/ncol descriptor of variant segments
+__global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
+{
+    const MsaView& mv = p.mv;
+    const u64 nseg = *p.nseg_ptr;
+    for (u64 seg = blockIdx.x * (u64)blockDim.x + threadIdx.x; seg < nseg; seg += (u64)gridDim.x * blockDim.x) {
+        const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
+        if (!mv.vbit(a)) {
+            p.eds_len[seg] = 2 + (b - a);
+            p.seds_len[seg] = 3;
+            p.segmeta[seg] = 0;
+            continue;
+        }
+        u64 meta = 0;                                     // 0 on a variant segment: not fast
+        const u64 ncol = b - a;
+        if (ncol <= 64) {
+            const u64 s0 = mv.slot(a);
+            bool pure = true, contig = true;
+            for (u64 c = a + 1; c < b; c++) {
+                pure = pure && mv.vbit(c);
+                if (pure) contig = contig && mv.slot(c) == s0 + (c - a);
+            }
+            if (pure) meta = META_FAST | (contig ? 0 : META_SCATTER) | (ncol << 48) | s0;
+        }
+        p.segmeta[seg] = meta;
+    }
+}
+
+__device__ __forceinline__ uint32_t bytes_ne_mask(uint32_t a, uint32_t b)   // 0xFF where bytes differ
+{
+    uint32_t x = a ^ b;
+    uint32_t t = ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u) >> 7;
+    return t * 0xffu;
+}
+__device__ __forceinline__ uint4 bytes_eq_mask(const uint4& a, uint32_t cccc)
+{
+    return make_uint4(~bytes_ne_mask(a.x, cccc), ~bytes_ne_mask(a.y, cccc), ~bytes_ne_mask(a.z, cccc),
+                      ~bytes_ne_mask(a.w, cccc));
+}
+__device__ __forceinline__ bool any4(const uint4& v) { return (v.x | v.y | v.z | v.w) != 0; }
+__device__ __forceinline__ u32 first_byte_index(const uint4& m)   // m bytes are 0x00 / 0xFF
+{
+    return m.x ? (u32)__builtin_ctz(m.x) >> 3
+               : m.y ? 4u + ((u32)__builtin_ctz(m.y) >> 3)
+                     : m.z ? 8u + ((u32)__builtin_ctz(m.z) >> 3) : m.w ? 12u + ((u32)__builtin_ctz(m.w) >> 3) : 16u;
+}
+// byte `idx` (wave-uniform) of lane `leader`'s 16-byte vector, as a wave-uniform value
+__device__ __forceinline__ u32 leader_byte(const uint4& v, int leader, u32 idx)
+{
+    const u32 x = (u32)__builtin_amdgcn_readlane((int)v.x, leader), y = (u32)__builtin_amdgcn_readlane((int)v.y, leader);
+    const u32 z = (u32)__builtin_amdgcn_readlane((int)v.z, leader), w = (u32)__builtin_amdgcn_readlane((int)v.w, leader);
+    const u32 d = idx < 8 ? (idx < 4 ? x : y) : (idx < 12 ? z : w);
+    return (d >> ((idx & 3) * 8)) & 0xffu;
+}
+// '-' and '\n' contribute nothing to a row's string (msa_transforms.cpp:283): normalise to 0
+template <bool CHECK_NL>
+__device__ __forceinline__ uint4 normalise_col(const uint4& c, const uint4& vmask, u32& saw_nl)
+{
+    uint4 gap = bytes_eq_mask(c, 0x2d2d2d2du);
+    if (CHECK_NL) {
+        uint4 nl = bytes_eq_mask(c, 0x0a0a0a0au);
+        if (any4(make_uint4(nl.x & vmask.x, nl.y & vmask.y, nl.z & vmask.z, nl.w & vmask.w))) saw_nl = 1;
+        gap.x |= nl.x; gap.y |= nl.y; gap.z |= nl.z; gap.w |= nl.w;
+    }
+    return make_uint4(c.x & ~gap.x, c.y & ~gap.y, c.z & ~gap.z, c.w & ~gap.w);
+}
+
+constexpr int KCAP = 64;          // distinct strings per fast segment (group g lives in lane g)
+struct FastGroups {
+    uint4 gid;            // byte i = group of row i*64+lane (0xFF: no such row)
+    u32 k;                // number of distinct strings (wave-uniform)
+    u32 sumlen;           // sum of their lengths
+    // lane g holds the state of group g
+    u64 key_lo, key_hi;   // ncol == 1: the letter; else 96-bit hash of the gap-stripped string
+    u32 rep;              // representative row (first row of the group in row order)
+    u32 len;              // length of the group's string
+};
+
+// lane-private validity mask: byte i = 0xFF iff row i*64+lane exists
+__device__ __forceinline__ uint4 fast_valid_mask(u32 lane, u32 S)
+{
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if ((u32)i * 64u + lane < S) w0 |= 0xffu << (i * 8);
+        if ((u32)(i + 4) * 64u + lane < S) w1 |= 0xffu << (i * 8);
+        if ((u32)(i + 8) * 64u + lane < S) w2 |= 0xffu << (i * 8);
+        if ((u32)(i + 12) * 64u + lane < S) w3 |= 0xffu << (i * 8);
+    }
+    return make_uint4(w0, w1, w2, w3);
+}
+
+// the not yet grouped row that comes first in row order (i, lane): returns i (uniform) and its lane
+__device__ __forceinline__ u32 first_remaining(const uint4& rm, int& leader)
+{
+    const u32 i0 = first_byte_index(rm);
+    u64 bl = 0;
+    u32 t = 0;
+    for (; t < 16; t++) { bl = ballot64(i0 == t); if (bl) break; }
+    leader = __builtin_ctzll(bl);
+    return t;
+}
+
+// assign the rows in `eq` to the group with key (klo,khi): an existing one or a new one.
+// Returns false when KCAP is exceeded.
+__device__ __forceinline__ bool fast_assign(FastGroups& G, uint4& rm, const uint4& eq, u64 klo, u64 khi,
+                                            u32 len, u32 lane, u32 rep_row)
+{
+    const u64 hit = ballot64(lane < G.k && G.key_lo == klo && G.key_hi == khi);
+    u32 gsel;
+    if (hit) gsel = (u32)__builtin_ctzll(hit);
+    else {
+        if (G.k >= (u32)KCAP) return false;
+        gsel = G.k;
+        if (lane == gsel) { G.key_lo = klo; G.key_hi = khi; G.rep = rep_row; G.len = len; }
+        G.k++;
+        G.sumlen += len;
+    }
+    const uint32_t gg = gsel * 0x01010101u;
+    G.gid.x = (G.gid.x & ~eq.x) | (eq.x & gg); G.gid.y = (G.gid.y & ~eq.y) | (eq.y & gg);
+    G.gid.z = (G.gid.z & ~eq.z) | (eq.z & gg); G.gid.w = (G.gid.w & ~eq.w) | (eq.w & gg);
+    rm.x &= ~eq.x; rm.y &= ~eq.y; rm.z &= ~eq.z; rm.w &= ~eq.w;
+    return true;
+}
+
+// Group the rows of a fast segment (msa_transforms.cpp:262-293: distinct gap-stripped strings in
+// order of first appearance).  Returns false when the segment must take the generic path.
+//   one column : exact, SWAR byte compares.
+//   2..64 cols : every row's gap-stripped string is hashed once (3 multiplicative chains with 24-bit
+//                state, v_mad_u32_u24 = full rate, fed only by its non-gap letters, + its length),
+//                rows are grouped by that signature.  The cost does not depend on the number of
+//                groups; two different strings of one segment collide with probability ~2^-72.
+template <bool CHECK_NL>
+__device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 meta, const uint4& col0, u32 lane,
+                                           const uint4& vmask, FastGroups& G, u32& saw_nl)
+{
+    const u32 ncol = (u32)(meta >> 48) & 0xffu;
+    uint4 rm = vmask;
+    G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
+    G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
+
+    if (ncol == 1) {
+        const uint4 col = normalise_col<CHECK_NL>(col0, vmask, saw_nl);
+        while (ballot64(any4(rm))) {
+            int leader;
+            const u32 i0 = first_remaining(rm, leader);
+            const u32 c = leader_byte(col, leader, i0);
+            uint4 eq = bytes_eq_mask(col, c * 0x01010101u);
+            eq.x &= rm.x; eq.y &= rm.y; eq.z &= rm.z; eq.w &= rm.w;
+            if (!fast_assign(G, rm, eq, (u64)c, 0ull, c ? 1u : 0u, lane, i0 * 64u + (u32)leader)) return false;
+        }
+        return true;
+    }
+
+    // ---- phase A: signatures of the 16 rows of this lane
+    u32 h1[16], h2[16], h3[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { h1[i] = 0x811c9dc5u; h2[i] = 0x9e3779b9u; h3[i] = 0x7f4a7c15u; }
+    uint4 lenv = make_uint4(0, 0, 0, 0);               // byte i = letters of row i so far
+    const u64 slot0 = meta & META_SLOT;
+    const bool scatter = (meta & META_SCATTER) != 0;
+    const uint8_t* cbase = mv.vc + slot0 * (u64)mv.Spad + (u64)lane * mv.Gp;
+#define EDSX_H(I)                                                                                 \
+        {                                                                                         \
+            const u32 bch = byte_at<I>(cn);                                                       \
+            h1[I] = bch ? __umul24(h1[I], 0x9e3779u) + bch : h1[I];                               \
+            h2[I] = bch ? __umul24(h2[I], 0x85ebcbu) + (bch << 3) + 1u : h2[I];                   \
+            h3[I] = bch ? __umul24(h3[I] ^ (h3[I] >> 11), 0xc2b2afu) + bch : h3[I];               \
+        }
+#define EDSX_HASHCOL(colv)                                                                        \
+        {                                                                                         \
+            const uint4 cn = normalise_col<CHECK_NL>(colv, vmask, saw_nl);                        \
+            const uint4 nz = make_uint4(bytes_ne_mask(cn.x, 0u), bytes_ne_mask(cn.y, 0u), bytes_ne_mask(cn.z, 0u), \
+                                        bytes_ne_mask(cn.w, 0u));                                 \
+            lenv.x += nz.x & 0x01010101u; lenv.y += nz.y & 0x01010101u;                           \
+            lenv.z += nz.z & 0x01010101u; lenv.w += nz.w & 0x01010101u;                           \
+            EDSX_H(0) EDSX_H(1) EDSX_H(2) EDSX_H(3) EDSX_H(4) EDSX_H(5) EDSX_H(6) EDSX_H(7)       \
+            EDSX_H(8) EDSX_H(9) EDSX_H(10) EDSX_H(11) EDSX_H(12) EDSX_H(13) EDSX_H(14) EDSX_H(15) \
+        }
+    auto col_ptr = [&](u32 c) -> const uint8_t* {
+        return scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + (u64)lane * mv.Gp : cbase + (u64)c * mv.Spad;
+    };
+#ifndef EDSX_PHASEA
+#define EDSX_PHASEA 1
+#endif
+#if EDSX_PHASEA == 0
+    // rolled, three columns in flight (register rotation)
+    uint4 nxt1 = ncol > 1 ? load16u(col_ptr(1)) : make_uint4(0, 0, 0, 0);
+    uint4 nxt2 = ncol > 2 ? load16u(col_ptr(2)) : make_uint4(0, 0, 0, 0);
+    uint4 cur_col = col0;
+    for (u32 c = 0; c < ncol; c++) {
+        const uint4 nxt3 = c + 3 < ncol ? load16u(col_ptr(c + 3)) : make_uint4(0, 0, 0, 0);
+        EDSX_HASHCOL(cur_col)
+        cur_col = nxt1; nxt1 = nxt2; nxt2 = nxt3;
+    }
+#elif EDSX_PHASEA == 1
+    // batches of 4 columns: 4 loads in flight, then 4 hash bodies
+    for (u32 c0 = 0; c0 < ncol; c0 += 4) {
+        uint4 cvs[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            cvs[j] = make_uint4(0, 0, 0, 0);
+            if (c0 + j < ncol) cvs[j] = (c0 + j == 0) ? col0 : load16u(col_ptr(c0 + j));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (c0 + j < ncol) EDSX_HASHCOL(cvs[j])
+        }
+    }
+#else
+    // rolled, load and use (latency hidden by the other waves only)
+    for (u32 c = 0; c < ncol; c++) {
+        const uint4 cv = c == 0 ? col0 : load16u(col_ptr(c));
+        EDSX_HASHCOL(cv)
+    }
+#endif
+#undef EDSX_HASHCOL
+#undef EDSX_H
+    // ---- phase B: groups in order of first appearance
+    while (ballot64(any4(rm))) {
+        int leader;
+        const u32 i0 = first_remaining(rm, leader);
+        u32 m1 = 0, m2 = 0, m3 = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            m1 = (i0 == (u32)i) ? h1[i] : m1; m2 = (i0 == (u32)i) ? h2[i] : m2; m3 = (i0 == (u32)i) ? h3[i] : m3;
+        }
+        const u32 r1 = (u32)__builtin_amdgcn_readlane((int)m1, leader), r2 = (u32)__builtin_amdgcn_readlane((int)m2, leader);
+        const u32 r3 = (u32)__builtin_amdgcn_readlane((int)m3, leader);
+        const u32 len = leader_byte(lenv, leader, i0);
+        uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (h1[i] == r1 && h2[i] == r2 && h3[i] == r3) e0 |= 0xffu << (i * 8);
+            if (h1[i + 4] == r1 && h2[i + 4] == r2 && h3[i + 4] == r3) e1 |= 0xffu << (i * 8);
+            if (h1[i + 8] == r1 && h2[i + 8] == r2 && h3[i + 8] == r3) e2 |= 0xffu << (i * 8);
+            if (h1[i + 12] == r1 && h2[i + 12] == r2 && h3[i + 12] == r3) e3 |= 0xffu << (i * 8);
+        }
+        // rows of equal signature but other length cannot exist in practice; the length is part of the key
+        const uint4 lm = bytes_eq_mask(lenv, len * 0x01010101u);
+        const uint4 eq = make_uint4(e0 & rm.x & lm.x, e1 & rm.y & lm.y, e2 & rm.z & lm.z, e3 & rm.w & lm.w);
+        if (!fast_assign(G, rm, eq, ((u64)r2 << 32) | r1, ((u64)len << 32) | r3, len, lane, i0 * 64u + (u32)leader))
+            return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ u32 packed_len(u64 k) { return k ? (u32)(71 - __builtin_clzll(k)) >> 3 : 0u; }
+
+__device__ __forceinline__ uint4 fast_load_col(const MsaView& mv, u64 meta, u32 lane)
+{
+    if (!(meta & META_FAST)) return make_uint4(0, 0, 0, 0);
+    return load16u(mv.vc + (meta & META_SLOT) * (u64)mv.Spad + (u64)lane * mv.Gp);
+}
+
+#ifdef EDSX_DIAG
+__device__ u64 g_diag[2][8][3];      // [kernel][class][sum cycles, count, max cycles]
+__device__ u64 g_stage[8];           // emit, class 0: group, ids, flush, eds ; count class 2: phaseA, phaseB
+#define DIAG_STAMP(var) const u64 var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+__device__ __forceinline__ void diag_add(int kern, u32 ncol, u32 k, u64 cyc, u32 lane)
+{
+    if (lane) return;
+    int cls = (ncol == 1 ? 0 : (ncol <= 8 ? 2 : 4)) + (k > 4 ? 1 : 0);
+    if (k > 16) cls = 6 + (ncol > 8 ? 1 : 0);
+    atomicAdd(&g_diag[kern][cls][0], cyc);
+    atomicAdd(&g_diag[kern][cls][1], 1ull);
+    atomicMax(&g_diag[kern][cls][2], cyc);
+}
+#endif
+
+// K3 fast: sizes of the variant segments.  Variant and common segments alternate, so the
+// variant ones are seg = 2*vi + p0.
+__global__ void __launch_bounds__(256) k_seg_count_fast(FastParams p)
+{
+    const MsaView& mv = p.mv;
+    if (mv.hdr->status) return;
+    const u32 lane = threadIdx.x & 63;
+    const u64 nseg = *p.nseg_ptr;
+    const u64 p0 = mv.vbit(0) ? 0 : 1;
+    const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
+    const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    const uint4 vmask = fast_valid_mask(lane, mv.S);
+    u32 saw_nl = 0;
+    // everything indexed by the segment is wave-uniform: say so (readfirstlane), or hipcc predicates
+    // every use per lane and serialises the column loads
+    u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + uniform32(threadIdx.x >> 6);
+    u64 meta = vi < nvs ? uniform64(p.segmeta[2 * vi + p0]) : 0;
+    u64 meta_n = vi + nw < nvs ? uniform64(p.segmeta[2 * (vi + nw) + p0]) : 0;
+    uint4 col = fast_load_col(mv, meta, lane);
+    while (vi < nvs) {
+        const u64 seg = 2 * vi + p0;
+        // prefetch: next segment's first column and the descriptor after it
+        const uint4 col_n = fast_load_col(mv, meta_n, lane);
+        const u64 meta_nn = vi + 2 * nw < nvs ? uniform64(p.segmeta[2 * (vi + 2 * nw) + p0]) : 0;
+
+#ifdef EDSX_DIAG
+        const u64 t_diag = __builtin_amdgcn_s_memtime();
+#endif
+        bool fast = (meta & META_FAST) != 0;
+        FastGroups G;
+        if (fast) fast = fast_group<true>(mv, (meta & META_SCATTER) ? uniform64(p.seg_start[seg]) : 0, meta, col, lane, vmask, G, saw_nl);
+        if (fast) {
+            if (lane == 0) {
+                p.eds_len[seg] = 2 + (u64)(G.k - 1) + G.sumlen;
+                p.seds_len[seg] = (u64)G.k + p.tok_total;
+            }
+        } else if (lane == 0) {
+            p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;
+        }
+#ifdef EDSX_DIAG
+        if (fast) diag_add(0, (u32)(meta >> 48) & 0xff, G.k, __builtin_amdgcn_s_memtime() - t_diag, lane);
+#endif
+        vi += nw; meta = meta_n; meta_n = meta_nn; col = col_n;
+    }
+    if (saw_nl) atomicOr(&mv.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));
+}
+
+// ---- K5 fast: .seds / .eds text of the variant segments.  msa_transforms.cpp:297-317.
+//   LDS per workgroup: token table tok[1024] (u64: "ddd," + length in byte 7) | per-wave staging.
+//   Ids of block i (rows i*64 .. i*64+63) are i*64+1 .. i*64+64: 3 digits for blocks 2..14; the
+//   digit count changes inside block 0 (ids 1-9 | 10-64), block 1 (65-99 | 100-128) and block 15
+//   (961-999 | 1000-1024): there the lanes below SHORT have the shorter token.
+constexpr int FAST_STAGE = 4608;   // >= 16 + KCAP + tokens of 1024 rows (4013 + 250 + 16), multiple of 256
+
+template <int I> struct IdBlock {
+    static constexpr u32 TLMIN = I == 0 ? 2u : (I == 1 ? 3u : 4u);
+    static constexpr bool MIXED = I == 0 || I == 1 || I == 15;
+    static constexpr u64 SHORT = I == 0 ? ((1ull << 9) - 1) : (I == 1 ? ((1ull << 35) - 1) : (I == 15 ? ((1ull << 39) - 1) : ~0ull));
+};
+
+__device__ __forceinline__ u32 gid_byte(const uint4& gid, u32 i)       // i is wave-uniform
+{
+    const u32 w = i < 8 ? (i < 4 ? gid.x : gid.y) : (i < 12 ? gid.z : gid.w);
+    return (w >> ((i & 3) * 8)) & 0xffu;
+}
+
+// one block of 64 rows: where does this lane's token go, and advance the group cursors.
+//   cursors: registers (K compile-time, <= 4) ...
+template <int K, bool MIXED>
+__device__ __forceinline__ u32 block_offsets(u32 gi, u32 (&cur)[4], u32 tlmin, u64 shortm)
+{
+    u32 off = 0;
+#pragma unroll
+    for (int g = 0; g < K; g++) {
+        const u64 m = ballot64(gi == (u32)g);
+        u32 pre = mbcnt(m) * tlmin;
+        u32 tot = (u32)__builtin_popcountll(m) * tlmin;
+        if (MIXED) { pre += mbcnt(m & ~shortm); tot += (u32)__builtin_popcountll(m & ~shortm); }
+        off = (gi == (u32)g) ? cur[g] + pre : off;
+        cur[g] += tot;
+    }
+    return off;
+}
+//   ... or lane g's register cur_l (K run-time)
+template <bool MIXED>
+__device__ __forceinline__ u32 block_offsets_dyn(u32 gi, u32 k, u32& cur_l, u32 tlmin, u64 shortm, u32 lane)
+{
+    u32 off = 0;
+    for (u32 g = 0; g < k; g++) {
+        const u64 m = ballot64(gi == g);
+        if (!m) continue;
+        const u32 c = (u32)__builtin_amdgcn_readlane((int)cur_l, (int)g);
+        u32 pre = mbcnt(m) * tlmin;
+        u32 tot = (u32)__builtin_popcountll(m) * tlmin;
+        if (MIXED) { pre += mbcnt(m & ~shortm); tot += (u32)__builtin_popcountll(m & ~shortm); }
+        off = (gi == g) ? c + pre : off;
+        cur_l = (lane == g) ? c + tot : cur_l;
+    }
+    return off;
+}
+
+// Token text -> LDS.  Byte stores only: a misaligned ds_write_b32/b16 is replayed lane by lane on
+// gfx950 (measured: ~7000 cycles per wave instruction), four aligned byte stores are ~50x cheaper.
+template <bool MIXED>
+__device__ __forceinline__ void write_token(uint8_t* dst, u64 t)
+{
+    dst[0] = (uint8_t)t; dst[1] = (uint8_t)(t >> 8);
+    if (!MIXED) { dst[2] = (uint8_t)(t >> 16); dst[3] = (uint8_t)(t >> 24); return; }
+    const u32 tl = (u32)(t >> 56);
+    if (tl >= 3) dst[2] = (uint8_t)(t >> 16);
+    if (tl >= 4) dst[3] = (uint8_t)(t >> 24);
+    if (tl >= 5) dst[4] = (uint8_t)(t >> 32);
+}
+
+// Writes the id lists of the k groups into `text`; returns the number of bytes (= k + tokens).
+// K > 0: compile-time group count with cursors in registers; K == 0: run-time k (<= 64), the
+// cursor of group g lives in lane g.
+template <int K>
+__device__ __forceinline__ u32 fast_emit_ids(const uint4& gid, u32 k, uint8_t* text, const u64* tok_sh, u32 lane)
+{
+    u32 cur[4] = {0, 0, 0, 0};
+    u32 cur_l = 0, gstart_l = 0;
+    // pass 1: bytes per group
+    if (K) {
+        block_offsets<K, true>(gid_byte(gid, 0), cur, IdBlock<0>::TLMIN, IdBlock<0>::SHORT);
+        block_offsets<K, true>(gid_byte(gid, 1), cur, IdBlock<1>::TLMIN, IdBlock<1>::SHORT);
+        for (u32 i = 2; i < 15; i++) block_offsets<K, false>(gid_byte(gid, i), cur, 4u, ~0ull);
+        block_offsets<K, true>(gid_byte(gid, 15), cur, IdBlock<15>::TLMIN, IdBlock<15>::SHORT);
+    } else {
+        block_offsets_dyn<true>(gid_byte(gid, 0), k, cur_l, IdBlock<0>::TLMIN, IdBlock<0>::SHORT, lane);
+        block_offsets_dyn<true>(gid_byte(gid, 1), k, cur_l, IdBlock<1>::TLMIN, IdBlock<1>::SHORT, lane);
+        for (u32 i = 2; i < 15; i++) block_offsets_dyn<false>(gid_byte(gid, i), k, cur_l, 4u, ~0ull, lane);
+        block_offsets_dyn<true>(gid_byte(gid, 15), k, cur_l, IdBlock<15>::TLMIN, IdBlock<15>::SHORT, lane);
+    }
+    // group starts
+    u32 run = 0;
+    u32 gstart[4] = {0, 0, 0, 0};
+    if (K) {
+#pragma unroll
+        for (int g = 0; g < K; g++) { const u32 t = cur[g]; gstart[g] = run; cur[g] = run + 1; run += 1 + t; }
+    } else {
+        const u32 mine = lane < k ? 1u + cur_l : 0u;      // bytes of group `lane`
+        u32 incl = mine;
+        for (int o = 1; o < 64; o <<= 1) { u32 a = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += a; }
+        gstart_l = incl - mine;
+        cur_l = gstart_l + 1;
+        run = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    // pass 2: tokens, all lanes active, exact-length LDS writes
+#define EDSX_BLK(I, MIXED_)                                                                       \
+    {                                                                                             \
+        const u32 gi = gid_byte(gid, I);                                                          \
+        const u32 off = K ? block_offsets<K, MIXED_>(gi, cur, MIXED_ ? IdBlock<(I) & 15>::TLMIN : 4u, \
+                                                     MIXED_ ? IdBlock<(I) & 15>::SHORT : ~0ull)   \
+                          : block_offsets_dyn<MIXED_>(gi, k, cur_l, MIXED_ ? IdBlock<(I) & 15>::TLMIN : 4u, \
+                                                      MIXED_ ? IdBlock<(I) & 15>::SHORT : ~0ull, lane); \
+        if (gi != 0xffu) write_token<MIXED_>(text + off, tok_sh[(I) * 64u + lane]);               \
+    }
+    EDSX_BLK(0, true)
+    EDSX_BLK(1, true)
+    for (u32 i = 2; i < 15; i++) {
+        const u32 gi = gid_byte(gid, i);
+        const u32 off = K ? block_offsets<K, false>(gi, cur, 4u, ~0ull) : block_offsets_dyn<false>(gi, k, cur_l, 4u, ~0ull, lane);
+        if (gi != 0xffu) write_token<false>(text + off, tok_sh[i * 64u + lane]);
+    }
+    EDSX_BLK(15, true)
+#undef EDSX_BLK
+    // braces (after the tokens: the closing one replaces the last ',')
+    if (K) {
+        if (lane == 0) {
+#pragma unroll
+            for (int g = 0; g < K; g++) { text[gstart[g]] = '{'; text[cur[g] - 1] = '}'; }
+        }
+    } else if (lane < k) { text[gstart_l] = '{'; text[cur_l - 1] = '}'; }
+    return run;
+}
+
+__global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
+{
+    __shared__ __attribute__((aligned(16))) u64 tok_sh[1024];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_sh[4][FAST_STAGE];
+    const MsaView& mv = p.mv;
+    if (mv.hdr->status) return;
+    const u32 lane = threadIdx.x & 63, wv = uniform32(threadIdx.x >> 6);
+    for (u32 r = threadIdx.x; r < 1024; r += 256) {
+        u32 id = r + 1, nd = ndigits(id);
+        u64 t = 0;
+        u32 v = id;
+        for (int i = (int)nd - 1; i >= 0; i--) { t |= (u64)('0' + v % 10u) << (8 * i); v /= 10u; }
+        t |= (u64)',' << (8 * nd);
+        tok_sh[r] = t | ((u64)(nd + 1) << 56);
+    }
+    __syncthreads();
+    uint8_t* stage = stage_sh[wv];
+
+    const u64 nseg = *p.nseg_ptr;
+    const u64 p0 = mv.vbit(0) ? 0 : 1;
+    const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
+    const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    const uint4 vmask = fast_valid_mask(lane, mv.S);
+    u32 saw_nl = 0;
+    u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + uniform32(threadIdx.x >> 6);
+    u64 meta = vi < nvs ? uniform64(p.segmeta[2 * vi + p0]) : 0;
+    u64 meta_n = vi + nw < nvs ? uniform64(p.segmeta[2 * (vi + nw) + p0]) : 0;
+    uint4 col = fast_load_col(mv, meta, lane);
+    u64 goff = vi < nvs ? uniform64(p.seds_len[2 * vi + p0]) : 0;     // offsets after the scans
+    u64 eoff = vi < nvs ? uniform64(p.eds_len[2 * vi + p0]) : 0;
+    while (vi < nvs) {
+        const u64 seg = 2 * vi + p0;
+        const uint4 col_n = fast_load_col(mv, meta_n, lane);
+        const u64 meta_nn = vi + 2 * nw < nvs ? uniform64(p.segmeta[2 * (vi + 2 * nw) + p0]) : 0;
+        const u64 goff_n = vi + nw < nvs ? uniform64(p.seds_len[2 * (vi + nw) + p0]) : 0;
+        const u64 eoff_n = vi + nw < nvs ? uniform64(p.eds_len[2 * (vi + nw) + p0]) : 0;
+
+#ifdef EDSX_DIAG
+        const u64 t_diag = __builtin_amdgcn_s_memtime();
+#endif
+        bool fast = (meta & META_FAST) != 0;
+        FastGroups G;
+        if (fast) fast = fast_group<false>(mv, (meta & META_SCATTER) ? uniform64(p.seg_start[seg]) : 0, meta, col, lane, vmask, G, saw_nl);
+#ifdef EDSX_DIAG
+        DIAG_STAMP(t_g);
+        u64 t_i = t_g, t_f = t_g;
+#endif
+        if (fast) {
+            const u32 sh = (u32)goff & 15u;
+            uint8_t* text = stage + sh;                    // LDS offset == global offset (mod 16)
+            u32 n;
+            switch (G.k) {
+                case 1: n = fast_emit_ids<1>(G.gid, 1, text, tok_sh, lane); break;
+                case 2: n = fast_emit_ids<2>(G.gid, 2, text, tok_sh, lane); break;
+                case 3: n = fast_emit_ids<3>(G.gid, 3, text, tok_sh, lane); break;
+                case 4: n = fast_emit_ids<4>(G.gid, 4, text, tok_sh, lane); break;
+                default: n = fast_emit_ids<0>(G.gid, G.k, text, tok_sh, lane); break;
+            }
+#ifdef EDSX_DIAG
+            { DIAG_STAMP(tt); t_i = tt; }
+#endif
+            // ---- flush LDS -> HBM: aligned 16-byte blocks, byte stores for the ragged ends
+            uint8_t* gdst = p.seds + (goff - sh);          // 16-byte aligned image of `stage`
+            const u32 endo = sh + n;
+            const u32 body0 = sh ? 16u : 0u, body1 = endo & ~15u;
+            if (sh && lane < 16) { u32 o = lane; if (o >= sh && o < endo) gdst[o] = stage[o]; }
+            for (u32 o = body0 + lane * 16u; o + 16u <= body1; o += 1024u)
+                *reinterpret_cast<uint4*>(gdst + o) = *reinterpret_cast<const uint4*>(stage + o);
+            {
+                const u32 t0 = body1 > body0 ? body1 : body0;
+                if (lane < 16) { u32 o = t0 + lane; if (o < endo) gdst[o] = stage[o]; }
+            }
+#ifdef EDSX_DIAG
+            { DIAG_STAMP(tt); t_f = tt; }
+#endif
+            // ---- eds: "{" s0 "," s1 ... "}"
+            {
+                uint8_t* e = p.eds + eoff;
+                if (lane == 0) e[0] = '{';
+                u32 eo = 1;
+                const u32 ncol = (u32)(meta >> 48) & 0xffu;
+                for (u32 g = 0; g < G.k; g++) {
+                    u32 len;
+                    if (ncol == 1) {
+                        const u32 c = (u32)__builtin_amdgcn_readlane((int)(u32)G.key_lo, (int)g);
+                        len = c ? 1u : 0u;
+                        if (lane == 0 && c) e[eo] = (uint8_t)c;
+                    } else {                              // lane = column: the representative row's letters
+                        const u32 r = (u32)__builtin_amdgcn_readlane((int)G.rep, (int)g);
+                        u32 ch = 0;
+                        if (lane < ncol) {
+                            const u64 sl = (meta & META_SCATTER) ? mv.slot(p.seg_start[seg] + lane) : (meta & META_SLOT) + lane;
+                            ch = mv.vc[sl * (u64)mv.Spad + vc_pos(r, mv.Gp)];
+                            if (ch == '-' || ch == '\n') ch = 0;
+                        }
+                        const u64 m = ballot64(ch != 0);
+                        len = (u32)__builtin_popcountll(m);
+                        if (ch) e[eo + mbcnt(m)] = (uint8_t)ch;
+                    }
+                    if (lane == 0) e[eo + len] = (g + 1 < G.k) ? ',' : '}';
+                    eo += len + 1;
+                }
+            }
+        }
+#ifdef EDSX_DIAG
+        if (fast) {
+            const u64 t_e = __builtin_amdgcn_s_memtime();
+            diag_add(1, (u32)(meta >> 48) & 0xff, G.k, t_e - t_diag, lane);
+            if (lane == 0 && ((meta >> 48) & 0xff) == 1 && G.k <= 4) {
+                atomicAdd(&g_stage[0], t_g - t_diag); atomicAdd(&g_stage[1], t_i - t_g);
+                atomicAdd(&g_stage[2], t_f - t_i); atomicAdd(&g_stage[3], t_e - t_f);
+            }
+        }
+#endif
+        vi += nw; meta = meta_n; meta_n = meta_nn; col = col_n; goff = goff_n; eoff = eoff_n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static u64 token_total(u32 S)
@@ -793,10 +1480,10 @@ static const char* status_message(u64 st)
     return "MSA transform failed";
 }
 
-template <int T, int RPT, bool HOLD>
+template <int T, int RPT, bool HOLD, bool LANEROWS>
 static void launch_k1(const K1Params& p, size_t lds, hipStream_t st)
 {
-    auto kern = k_scan_extract<T, RPT, HOLD>;
+    auto kern = k_scan_extract<T, RPT, HOLD, LANEROWS>;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)p.ntiles), dim3(T), lds, st, p);
@@ -826,7 +1513,7 @@ void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t s
     if (h_.S > MAX_ROWS) throw FormatError(status_message(ST_TOO_MANY_ROWS));
 
     const u64 Draw = h_.Draw;
-    const u32 Spad = (u32)((h_.S + 15) / 16 * 16);
+    const u32 Spad = vc_pitch((u32)h_.S);
     {   // first guess for vc: 12.5 % variant columns; grown to the exact need on overflow
         u64 want = std::max<u64>(Draw / 8, 4096);
         if (want > Draw) want = Draw;
@@ -861,7 +1548,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     const uint8_t* d_msa = file_;
     const uint32_t l = l_;
     const u64 S = h_.S, L = h_.L, lw = h_.lw, Draw = h_.Draw;
-    const u32 Spad = (u32)((S + 15) / 16 * 16);
+    const u32 Spad = vc_pitch((u32)S);
     const u64 nwords = h_.nwords, nwords_raw = h_.nwords_raw;
 
     // ---- workspace (sized by the worst case "every column starts a run")
@@ -892,11 +1579,13 @@ void MsaPipeline::plan_body(hipStream_t st)
     K1Params kp;
     kp.file = d_msa; kp.row_start = rows_.as<u64>(); kp.hdr = dh;
     kp.Vraw = vraw_.as<u64>(); kp.word_slot = wslot_.as<u64>(); kp.vc = vc_.as<uint8_t>();
-    kp.vc_cap_cols = vc_cap_cols_; kp.Draw = Draw; kp.lw = lw; kp.S = (u32)S; kp.Spad = Spad;
+    kp.vc_cap_cols = vc_cap_cols_; kp.Draw = Draw; kp.lw = lw; kp.S = (u32)S; kp.Spad = Spad; kp.Gp = vc_rows_per_lane((u32)S);
     kp.cpr_log2 = cpr_log2; kp.cap_cols = (u32)(colbuf_bytes / Spad); kp.ntiles = ntiles;
     launch_timer_begin("k_scan_extract", st);
-    if (hold) launch_k1<T, RPT, true>(kp, colbuf_bytes, st);
-    else launch_k1<T, RPT, false>(kp, colbuf_bytes, st);
+    const bool lane_rows = hold && (T >> cpr_log2) == 64 && kp.Gp == 16;   // thread rows = one lane's 16 bytes
+    if (lane_rows) launch_k1<T, RPT, true, true>(kp, colbuf_bytes, st);
+    else if (hold) launch_k1<T, RPT, true, false>(kp, colbuf_bytes, st);
+    else launch_k1<T, RPT, false, false>(kp, colbuf_bytes, st);
     launch_timer_end(st);
 
     const u64* V = lw ? v_.as<u64>() : vraw_.as<u64>();
@@ -934,20 +1623,49 @@ void MsaPipeline::plan_body(hipStream_t st)
     // ---- K3 + K4: per-segment sizes, offsets
     mv_.file = d_msa; mv_.row_start = rows_.as<u64>(); mv_.V = V; mv_.Vraw = vraw_.as<u64>();
     mv_.word_slot = wslot_.as<u64>(); mv_.vc = vc_.as<uint8_t>(); mv_.hdr = dh; mv_.L = L; mv_.lw = lw;
-    mv_.S = (u32)S; mv_.Spad = Spad;
+    mv_.S = (u32)S; mv_.Spad = Spad; mv_.Gp = vc_rows_per_lane((u32)S);
     seg_start_p_ = seg_start; hseg_p_ = Hseg; segbase_p_ = segbase; nseg_p_ = d_nseg;
-    seg_lds_ = (size_t)18 * S + 64;
+    seg_lds_ = (size_t)18 * S + 64 + (S <= HT_MAX_ROWS ? HtLds::BYTES + 16 : 0);
 
+    const u64 tok_total = token_total((u32)S);
+    fast_ = S <= 1024;
     SegParams sp;
     sp.mv = mv_; sp.seg_start = seg_start; sp.nseg_ptr = d_nseg; sp.eds_len = eds_len_.as<u64>();
-    sp.seds_len = seds_len_.as<u64>(); sp.tok_total = token_total((u32)S);
+    sp.seds_len = seds_len_.as<u64>(); sp.tok_total = tok_total; sp.list = nullptr; sp.list_n = nullptr;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_count),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
-    TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
+    if (fast_) {
+        segmeta_.ensure(8 * (L + 2));
+        slow_list_.ensure(8 * (L / 2 + 2));
+        fp_.mv = mv_; fp_.seg_start = seg_start; fp_.nseg_ptr = d_nseg; fp_.segmeta = segmeta_.as<u64>();
+        fp_.eds_len = eds_len_.as<u64>(); fp_.seds_len = seds_len_.as<u64>();
+        fp_.slow_list = slow_list_.as<u64>(); fp_.slow_count = &dh->slow_n;
+        fp_.eds = nullptr; fp_.seds = nullptr; fp_.tok_total = tok_total;
+        EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, sizeof(u64), st));
+        TIMED("k_seg_meta", st, hipLaunchKernelGGL(k_seg_meta, dim3(4096), dim3(256), 0, st, fp_));
+        TIMED("k_seg_count_fast", st, hipLaunchKernelGGL(k_seg_count_fast, dim3(persistent_grid(
+                  reinterpret_cast<const void*>(k_seg_count_fast), 256, 0)), dim3(256), 0, st, fp_));
+        sp.list = slow_list_.as<u64>(); sp.list_n = &dh->slow_n;
+        TIMED("k_seg_count_slow", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
+    } else {
+        TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
+    }
     TIMED("scan_eds", st, exclusive_scan_u64(eds_len_.as<u64>(), eds_len_.as<u64>(), d_nseg, &dh->E,
                                              scan_tmp_.as<u64>(), st));
     TIMED("scan_seds", st, exclusive_scan_u64(seds_len_.as<u64>(), seds_len_.as<u64>(), d_nseg, &dh->Q,
                                               scan_tmp_.as<u64>(), st));
+}
+
+// workgroups that are resident at once: one persistent workgroup per slot
+unsigned MsaPipeline::persistent_grid(const void* kern, int threads, size_t dyn_lds) const
+{
+    int per_cu = 1, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, dyn_lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    int cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    return (unsigned)(cus * per_cu);
 }
 
 unsigned MsaPipeline::seg_grid() const
@@ -964,11 +1682,42 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
     ep.mv = mv_; ep.seg_start = seg_start_p_; ep.nseg_ptr = nseg_p_; ep.Hseg = hseg_p_; ep.segbase = segbase_p_;
     ep.eds_off = eds_len_.as<u64>(); ep.seds_off = seds_len_.as<u64>(); ep.eds = d_eds; ep.seds = d_seds;
     ep.nwords = h_.nwords;
+    ep.list = nullptr; ep.list_n = nullptr;
     TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_emit_variant),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
-    TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+    if (fast_) {
+        FastParams fp = fp_;
+        fp.eds = d_eds; fp.seds = d_seds;
+        TIMED("k_emit_variant_fast", st, hipLaunchKernelGGL(k_emit_variant_fast, dim3(persistent_grid(
+                  reinterpret_cast<const void*>(k_emit_variant_fast), 256, 0)), dim3(256), 0, st, fp));
+        ep.list = slow_list_.as<u64>(); ep.list_n = &hdr_.as<MsaHdr>()->slow_n;
+        TIMED("k_emit_variant_slow", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+    } else {
+        TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+    }
     EDSX_HIP(hipGetLastError());
+#ifdef EDSX_DIAG
+    {
+        EDSX_HIP(hipStreamSynchronize(st));
+        u64 h[2][8][3];
+        EDSX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof(h)));
+        const char* names[8] = {"1col k<=4", "1col k5-16", "2-8col k<=4", "2-8col k5-16", ">8col k<=4", ">8col k5-16", "<=8col k>16", ">8col k>16"};
+        for (int kk = 0; kk < 2; kk++)
+            for (int c = 0; c < 8; c++)
+                if (h[kk][c][1])
+                    fprintf(stderr, "DIAG %s %-14s n=%llu avg=%llu max=%llu total_Mcyc=%llu\n", kk ? "emit " : "count", names[c],
+                            h[kk][c][1], h[kk][c][0] / h[kk][c][1], h[kk][c][2], h[kk][c][0] / 1000000);
+        u64 stg[8];
+        EDSX_HIP(hipMemcpyFromSymbol(stg, HIP_SYMBOL(g_stage), sizeof(stg)));
+        if (h[1][0][1])
+            fprintf(stderr, "DIAG emit 1col stages avg: group=%llu ids=%llu flush=%llu eds=%llu\n", stg[0] / h[1][0][1],
+                    stg[1] / h[1][0][1], stg[2] / h[1][0][1], stg[3] / h[1][0][1]);
+        memset(h, 0, sizeof(h)); memset(stg, 0, sizeof(stg));
+        EDSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stage), stg, sizeof(stg)));
+        EDSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_diag), h, sizeof(h)));
+    }
+#endif
 }
 
 } // namespace edsx

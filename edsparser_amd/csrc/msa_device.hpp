@@ -40,12 +40,27 @@ struct MsaHdr {
     u64 nv;            // variant columns (slot allocator)
     u64 R, nseg, E, Q;
     u64 tmp_total;
+    u64 slow_n;        // variant segments left to the generic (workgroup-per-segment) kernels
 };
+
+// Row order inside one vc column.  Rows are dealt round-robin over the 64 lanes of a wave in
+// blocks of 1024 rows: row r sits at (r/1024)*1024 + (r%64)*Gp + (r%1024)/64, so ONE 16-byte load
+// at lane*Gp hands lane `lane` the rows lane, lane+64, lane+128, ...  (Gp = rows per lane = 16,
+// or ceil(S/64) when S <= 1024).  Consecutive row ids then sit in consecutive lanes, which makes
+// the id lists of the .seds a dense lane-parallel write.
+__host__ __device__ inline u32 vc_rows_per_lane(u32 S) { return S > 1024 ? 16u : (S + 63u) / 64u; }
+__host__ __device__ inline u32 vc_pitch(u32 S)
+{
+    const u32 gp = vc_rows_per_lane(S);
+    const u32 body = S > 1024 ? ((S + 1023u) / 1024u) * 1024u : 64u * gp;
+    return (body + 16u + 15u) / 16u * 16u;            // +16: the last lane may over-read 16 bytes
+}
+__host__ __device__ inline u32 vc_pos(u32 r, u32 gp) { return (r >> 10) * 1024u + (r & 63u) * gp + ((r & 1023u) >> 6); }
 
 // column access through V / vc (see msa_device.hip)
 struct MsaView {
     const uint8_t* file; const u64* row_start; const u64* V; const u64* Vraw; const u64* word_slot;
-    const uint8_t* vc; const MsaHdr* hdr; u64 L, lw; u32 S, Spad;
+    const uint8_t* vc; MsaHdr* hdr; u64 L, lw; u32 S, Spad, Gp;
     __device__ __forceinline__ u64 raw(u64 c) const { return lw ? c + c / lw : c; }
     __device__ __forceinline__ u32 vbit(u64 c) const { return (u32)(V[c >> 6] >> (c & 63)) & 1u; }
     __device__ __forceinline__ u64 slot(u64 c) const
@@ -55,6 +70,14 @@ struct MsaView {
         return word_slot[q >> 6] + __builtin_popcountll(bits);
     }
     __device__ __forceinline__ u32 ref_byte(u64 c) const { return file[row_start[0] + raw(c)]; }
+};
+
+// parameters of the wave-per-segment fast kernels (S <= 1024), see msa_device.hip
+struct FastParams {
+    MsaView mv; const u64* seg_start; const u64* nseg_ptr; u64* segmeta;
+    u64* eds_len; u64* seds_len;            // sizes (count pass) == offsets (emit pass, after the scans)
+    u64* slow_list; u64* slow_count;        // variant segments left to the generic kernels
+    uint8_t* eds; uint8_t* seds; u64 tok_total;
 };
 
 class MsaPipeline {
@@ -81,6 +104,7 @@ private:
     void clear_timers();
     void plan_body(hipStream_t st);
     unsigned seg_grid() const;
+    unsigned persistent_grid(const void* kern, int threads, size_t dyn_lds) const;
 
     const uint8_t* file_ = nullptr;
     size_t n_ = 0;
@@ -90,7 +114,7 @@ private:
     std::vector<TimedKernel> timed_;
 
     DevBuf hdr_, rows_, vraw_, v_, wslot_, vc_, hrun_, hseg_, cnt_, wbase_, segbase_, scan_tmp_,
-           run_start_, flag_, seg_start_, eds_len_, seds_len_;
+           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_;
     u64 vc_cap_cols_ = 0;
 
     // emit-time view
@@ -98,6 +122,8 @@ private:
     const u64* seg_start_p_ = nullptr; const u64* hseg_p_ = nullptr; const u64* segbase_p_ = nullptr;
     const u64* nseg_p_ = nullptr;
     size_t seg_lds_ = 0;
+    bool fast_ = false;
+    FastParams fp_{};
 };
 
 } // namespace edsx

@@ -91,7 +91,8 @@ int edsx_msa_emit_device(edsx_ctx* ctx, uint8_t* d_eds, uint8_t* d_seds, void* s
 
 /* Geometry of the last planned alignment (for reporting). */
 typedef struct {
-    uint64_t n_rows, n_cols, line_width, n_variant_cols, n_segments, msa_bytes;
+    uint64_t n_rows, n_cols, line_width, n_variant_cols, n_segments, msa_bytes,
+             n_slow_segments;   /* variant segments handled by the generic (slow) kernels */
 } edsx_msa_info;
 int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info);
 
