@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace edsx {
@@ -189,8 +190,13 @@ template <int I> __device__ __forceinline__ u32 byte_at(const uint4& v)
     return (w >> ((I & 3) * 8)) & 0xffu;
 }
 
-template <int T, int RPT, bool HOLD, bool LANEROWS>
-__global__ void __launch_bounds__(T) k_scan_extract(K1Params p)
+#ifdef EDSX_K1_NT
+#define EDSX_K1_LOAD load16u_nt
+#else
+#define EDSX_K1_LOAD load16u
+#endif
+template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW>
+__global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t colbuf[];
     __shared__ u32 D[256];
@@ -236,7 +242,7 @@ __global__ void __launch_bounds__(T) k_scan_extract(K1Params p)
 #pragma unroll
         for (int it = 0; it < RPT; it++) {
             const u32 r = sub + it * RI;
-            d[HOLD ? it : 0] = load16u(f + rs[r < p.S ? r : Sm1] + q);   // clamped: rows past S re-read row S-1
+            d[HOLD ? it : 0] = EDSX_K1_LOAD(f + rs[r < p.S ? r : Sm1] + q);   // clamped: rows past S re-read row S-1
             if constexpr (!HOLD) {
                 acc.x |= d[0].x ^ ref.x; acc.y |= d[0].y ^ ref.y; acc.z |= d[0].z ^ ref.z; acc.w |= d[0].w ^ ref.w;
             }
@@ -913,6 +919,10 @@ __device__ __forceinline__ uint4 normalise_col(const uint4& c, const uint4& vmas
 }
 
 constexpr int KCAP = 64;          // distinct strings per fast segment (group g lives in lane g)
+// Grouping record of a fast segment, written by the count kernel and read by the emit kernel
+// (so the rows are grouped once): 1024 group-id bytes in vc row order | rep[64] u16 | letter[64] u8
+// | k.  Indexed by the ordinal of the variant segment.
+constexpr u32 GREC_BYTES = 1280, GREC_REP = 1024, GREC_CHR = 1152, GREC_K = 1216;
 struct FastGroups {
     uint4 gid;            // byte i = group of row i*64+lane (0xFF: no such row)
     u32 k;                // number of distinct strings (wave-uniform)
@@ -1146,12 +1156,20 @@ __global__ void __launch_bounds__(256) k_seg_count_fast(FastParams p)
         bool fast = (meta & META_FAST) != 0;
         FastGroups G;
         if (fast) fast = fast_group<true>(mv, (meta & META_SCATTER) ? uniform64(p.seg_start[seg]) : 0, meta, col, lane, vmask, G, saw_nl);
+        uint8_t* rec = p.grec + vi * (u64)GREC_BYTES;
         if (fast) {
+            *reinterpret_cast<uint4*>(rec + lane * 16u) = G.gid;
+            if (lane < G.k) {
+                *reinterpret_cast<uint16_t*>(rec + GREC_REP + lane * 2u) = (uint16_t)G.rep;
+                rec[GREC_CHR + lane] = (uint8_t)G.key_lo;
+            }
             if (lane == 0) {
+                rec[GREC_K] = (uint8_t)G.k;
                 p.eds_len[seg] = 2 + (u64)(G.k - 1) + G.sumlen;
                 p.seds_len[seg] = (u64)G.k + p.tok_total;
             }
         } else if (lane == 0) {
+            rec[GREC_K] = 0;                              // not a fast segment
             p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;
         }
 #ifdef EDSX_DIAG
@@ -1315,26 +1333,35 @@ __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
     const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
     const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
     const uint4 vmask = fast_valid_mask(lane, mv.S);
-    u32 saw_nl = 0;
+    struct Rec { uint4 gid; u32 rep, chr, k; };
+    auto load_rec = [&](u64 v) -> Rec {
+        Rec r;
+        const uint8_t* rec = p.grec + v * (u64)GREC_BYTES;
+        r.gid = *reinterpret_cast<const uint4*>(rec + lane * 16u);
+        r.rep = *reinterpret_cast<const uint16_t*>(rec + GREC_REP + lane * 2u);
+        r.chr = rec[GREC_CHR + lane];
+        r.k = rec[GREC_K];
+        return r;
+    };
     u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + uniform32(threadIdx.x >> 6);
+    Rec rc = load_rec(vi < nvs ? vi : 0);
     u64 meta = vi < nvs ? uniform64(p.segmeta[2 * vi + p0]) : 0;
-    u64 meta_n = vi + nw < nvs ? uniform64(p.segmeta[2 * (vi + nw) + p0]) : 0;
-    uint4 col = fast_load_col(mv, meta, lane);
     u64 goff = vi < nvs ? uniform64(p.seds_len[2 * vi + p0]) : 0;     // offsets after the scans
     u64 eoff = vi < nvs ? uniform64(p.eds_len[2 * vi + p0]) : 0;
     while (vi < nvs) {
         const u64 seg = 2 * vi + p0;
-        const uint4 col_n = fast_load_col(mv, meta_n, lane);
-        const u64 meta_nn = vi + 2 * nw < nvs ? uniform64(p.segmeta[2 * (vi + 2 * nw) + p0]) : 0;
-        const u64 goff_n = vi + nw < nvs ? uniform64(p.seds_len[2 * (vi + nw) + p0]) : 0;
-        const u64 eoff_n = vi + nw < nvs ? uniform64(p.eds_len[2 * (vi + nw) + p0]) : 0;
-
+        // everything the next segment needs is requested one iteration ahead
+        const u64 vn = vi + nw < nvs ? vi + nw : vi;
+        const Rec rc_n = load_rec(vn);
+        const u64 meta_n = uniform64(p.segmeta[2 * vn + p0]);
+        const u64 goff_n = uniform64(p.seds_len[2 * vn + p0]);
+        const u64 eoff_n = uniform64(p.eds_len[2 * vn + p0]);
 #ifdef EDSX_DIAG
         const u64 t_diag = __builtin_amdgcn_s_memtime();
 #endif
-        bool fast = (meta & META_FAST) != 0;
         FastGroups G;
-        if (fast) fast = fast_group<false>(mv, (meta & META_SCATTER) ? uniform64(p.seg_start[seg]) : 0, meta, col, lane, vmask, G, saw_nl);
+        G.gid = rc.gid; G.k = uniform32(rc.k); G.rep = rc.rep; G.key_lo = rc.chr; G.key_hi = 0; G.sumlen = 0; G.len = 0;
+        const bool fast = G.k != 0;
 #ifdef EDSX_DIAG
         DIAG_STAMP(t_g);
         u64 t_i = t_g, t_f = t_g;
@@ -1406,7 +1433,7 @@ __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
             }
         }
 #endif
-        vi += nw; meta = meta_n; meta_n = meta_nn; col = col_n; goff = goff_n; eoff = eoff_n;
+        vi += nw; meta = meta_n; rc = rc_n; goff = goff_n; eoff = eoff_n;
     }
 }
 
@@ -1480,10 +1507,10 @@ static const char* status_message(u64 st)
     return "MSA transform failed";
 }
 
-template <int T, int RPT, bool HOLD, bool LANEROWS>
+template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW>
 static void launch_k1(const K1Params& p, size_t lds, hipStream_t st)
 {
-    auto kern = k_scan_extract<T, RPT, HOLD, LANEROWS>;
+    auto kern = k_scan_extract<T, RPT, HOLD, LANEROWS, MINW>;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)p.ntiles), dim3(T), lds, st, p);
@@ -1566,26 +1593,45 @@ void MsaPipeline::plan_body(hipStream_t st)
     eds_len_.ensure(8 * (L + 2));
     seds_len_.ensure(8 * (L + 2));
 
-    // ---- K1 geometry: largest tile whose rows fit the per-thread register budget
-    constexpr int T = 1024, RPT = 16;
+    // ---- K1 geometry.  A workgroup of T threads keeps RPT 16-byte chunks per thread in registers:
+    // rows per pass = T / CPR, tile width W = 16 * CPR columns.  Two workgroups per CU let one
+    // tile's extraction phase overlap the other's load phase.
+    //   cfg 0: T=1024 RPT=16  (1 workgroup/CU, widest tile)
+    //   cfg 1: T=512  RPT=16  (2 workgroups/CU)
+    //   cfg 2: T=1024 RPT=8   (2 workgroups/CU, <= 64 VGPRs)
+    static int cfg_env = -1;
+    if (cfg_env < 0) { const char* e = getenv("EDSX_K1"); cfg_env = e ? atoi(e) : 1; if (cfg_env < 0 || cfg_env > 2) cfg_env = 1; }
+    int cfg = cfg_env;
+    const int T = cfg == 1 ? 512 : 1024, RPT = cfg == 2 ? 8 : 16;
     u32 cpr_log2 = 8;
     while (cpr_log2 > 2 && (u64)RPT * (T >> cpr_log2) < S) cpr_log2--;
     const bool hold = (u64)RPT * (T >> cpr_log2) >= S;
     const u64 W = 16ull << cpr_log2;
     const u64 ntiles = (Draw + W - 1) / W;
-    const size_t colbuf_bytes = 96 * 1024;
+    const size_t colbuf_bytes = cfg == 0 ? 96 * 1024 : 64 * 1024;
     if (ntiles > 0x7fffffffull) throw FormatError("MSA too large for one launch");
+    if (colbuf_bytes < (size_t)S * 8) throw FormatError(status_message(ST_TOO_MANY_ROWS));
 
     K1Params kp;
     kp.file = d_msa; kp.row_start = rows_.as<u64>(); kp.hdr = dh;
     kp.Vraw = vraw_.as<u64>(); kp.word_slot = wslot_.as<u64>(); kp.vc = vc_.as<uint8_t>();
     kp.vc_cap_cols = vc_cap_cols_; kp.Draw = Draw; kp.lw = lw; kp.S = (u32)S; kp.Spad = Spad; kp.Gp = vc_rows_per_lane((u32)S);
     kp.cpr_log2 = cpr_log2; kp.cap_cols = (u32)(colbuf_bytes / Spad); kp.ntiles = ntiles;
+    if (kp.cap_cols == 0) throw FormatError(status_message(ST_TOO_MANY_ROWS));
     launch_timer_begin("k_scan_extract", st);
-    const bool lane_rows = hold && (T >> cpr_log2) == 64 && kp.Gp == 16;   // thread rows = one lane's 16 bytes
-    if (lane_rows) launch_k1<T, RPT, true, true>(kp, colbuf_bytes, st);
-    else if (hold) launch_k1<T, RPT, true, false>(kp, colbuf_bytes, st);
-    else launch_k1<T, RPT, false, false>(kp, colbuf_bytes, st);
+    const bool lane_rows = hold && RPT == 16 && (T >> cpr_log2) == 64 && kp.Gp == 16;   // thread rows = one lane's 16 bytes
+    if (cfg == 1) {
+        if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
+        else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
+        else launch_k1<512, 16, false, false, 4>(kp, colbuf_bytes, st);
+    } else if (cfg == 2) {
+        if (hold) launch_k1<1024, 8, true, false, 8>(kp, colbuf_bytes, st);
+        else launch_k1<1024, 8, false, false, 8>(kp, colbuf_bytes, st);
+    } else {
+        if (lane_rows) launch_k1<1024, 16, true, true, 4>(kp, colbuf_bytes, st);
+        else if (hold) launch_k1<1024, 16, true, false, 4>(kp, colbuf_bytes, st);
+        else launch_k1<1024, 16, false, false, 4>(kp, colbuf_bytes, st);
+    }
     launch_timer_end(st);
 
     const u64* V = lw ? v_.as<u64>() : vraw_.as<u64>();
@@ -1641,6 +1687,9 @@ void MsaPipeline::plan_body(hipStream_t st)
         fp_.eds_len = eds_len_.as<u64>(); fp_.seds_len = seds_len_.as<u64>();
         fp_.slow_list = slow_list_.as<u64>(); fp_.slow_count = &dh->slow_n;
         fp_.eds = nullptr; fp_.seds = nullptr; fp_.tok_total = tok_total;
+        // one record per variant segment; there are at most as many as variant columns
+        grec_.ensure(((size_t)vc_cap_cols_ + 2) * 1280);
+        fp_.grec = grec_.as<uint8_t>();
         EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, sizeof(u64), st));
         TIMED("k_seg_meta", st, hipLaunchKernelGGL(k_seg_meta, dim3(4096), dim3(256), 0, st, fp_));
         TIMED("k_seg_count_fast", st, hipLaunchKernelGGL(k_seg_count_fast, dim3(persistent_grid(

@@ -78,6 +78,7 @@ struct FastParams {
     u64* eds_len; u64* seds_len;            // sizes (count pass) == offsets (emit pass, after the scans)
     u64* slow_list; u64* slow_count;        // variant segments left to the generic kernels
     uint8_t* eds; uint8_t* seds; u64 tok_total;
+    uint8_t* grec;                          // grouping records (count -> emit)
 };
 
 class MsaPipeline {
@@ -114,7 +115,7 @@ private:
     std::vector<TimedKernel> timed_;
 
     DevBuf hdr_, rows_, vraw_, v_, wslot_, vc_, hrun_, hseg_, cnt_, wbase_, segbase_, scan_tmp_,
-           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_;
+           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, grec_;
     u64 vc_cap_cols_ = 0;
 
     // emit-time view
