@@ -1,6 +1,7 @@
 // capi.hip — the extern "C" boundary declared in include/edsx.h.  No exceptions cross it.
 #include "../../include/edsx.h"
 
+#include "merge_device.hpp"
 #include "msa_device.hpp"
 #include "synth.hpp"
 
@@ -15,6 +16,7 @@ struct edsx_ctx {
     int device = 0;
     std::string err;
     MsaPipeline msa;
+    MergePipeline merge;
     DevBuf d_in, d_eds, d_seds, synth_desc;
 };
 
@@ -140,12 +142,21 @@ int edsx_msa_transform(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint3
     });
 }
 
-int edsx_leds_merge(edsx_ctx* ctx, const uint8_t*, size_t, const uint8_t*, size_t, uint32_t, int,
-                    edsx_buf* leds, edsx_buf* seds_out)
+int edsx_leds_merge(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const uint8_t* seds, size_t seds_size,
+                    uint32_t context_len, int compact, edsx_buf* leds, edsx_buf* seds_out)
 {
     if (leds) { leds->data = nullptr; leds->size = 0; }
     if (seds_out) { seds_out->data = nullptr; seds_out->size = 0; }
-    return guarded(ctx, [&] { throw DeviceError("edsx_leds_merge: device path not built yet"); });
+    return guarded(ctx, [&] {
+        if (!leds || !seds_out || (!eds && eds_size)) throw ParamError("null argument");
+        std::string out, sout;
+        static const uint8_t none = 0;
+        ctx->merge.run(eds ? eds : &none, eds_size, seds, seds_size, context_len, compact != 0, out, sout, nullptr);
+        take(leds, out.size());
+        std::memcpy(leds->data, out.data(), out.size());
+        take(seds_out, sout.size());
+        std::memcpy(seds_out->data, sout.data(), sout.size());
+    });
 }
 
 int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t*, size_t, const uint8_t*, size_t, uint32_t,

@@ -95,24 +95,30 @@ __device__ __forceinline__ u32 ndigits(u32 v)
            (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
 }
 
-// ---- device-wide exclusive scan on u64 arrays, element count read from device memory -------
-// out[i] = sum(in[0..i)), *total = sum of all; in/out may alias.  Three grid-stride kernels.
+// ---- device-wide scans on u64 arrays, element count read from device memory -----------------
+// OP 0: exclusive sum (out[i] = sum(in[0..i)), *total = sum of all)
+// OP 1: inclusive max (out[i] = max(in[0..i]),  *total = max of all)
+// in/out may alias.  Three grid-stride kernels; tmp holds one u64 per SCAN_TILE elements.
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;   // 2048
 
-__device__ __forceinline__ u64 block_reduce_sum(u64 v, u64* sh /*[SCAN_THREADS/64]*/)
+template <int OP> __device__ __forceinline__ u64 scan_op(u64 a, u64 b) { return OP == 0 ? a + b : (a > b ? a : b); }
+
+template <int OP>
+__device__ __forceinline__ u64 block_reduce(u64 v, u64* sh /*[SCAN_THREADS/64]*/)
 {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    for (int o = 32; o > 0; o >>= 1) v = scan_op<OP>(v, __shfl_down(v, o, 64));
     int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) sh[w] = v;
     __syncthreads();
     u64 t = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += sh[i];
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t = scan_op<OP>(t, sh[i]);
     __syncthreads();
     return t;
 }
 
+template <int OP>
 static __global__ void k_scan_tile_sums(const u64* __restrict__ in, const u64* __restrict__ n_ptr,
                                         u64* __restrict__ bsum)
 {
@@ -124,14 +130,15 @@ static __global__ void k_scan_tile_sums(const u64* __restrict__ in, const u64* _
         u64 s = 0;
         for (int i = 0; i < SCAN_ITEMS; i++) {
             u64 idx = base + (u64)i * SCAN_THREADS + threadIdx.x;
-            if (idx < n) s += in[idx];
+            if (idx < n) s = scan_op<OP>(s, in[idx]);
         }
-        s = block_reduce_sum(s, sh);
+        s = block_reduce<OP>(s, sh);
         if (threadIdx.x == 0) bsum[t] = s;
     }
 }
 
 // single workgroup: exclusive scan of bsum[0..ntiles) in place, total -> *total
+template <int OP>
 static __global__ void k_scan_spine(u64* __restrict__ bsum, const u64* __restrict__ n_ptr,
                                     u64* __restrict__ total)
 {
@@ -149,19 +156,21 @@ static __global__ void k_scan_spine(u64* __restrict__ bsum, const u64* __restric
         for (int o = 1; o < (int)blockDim.x; o <<= 1) {       // Hillis-Steele inclusive
             u64 a = threadIdx.x >= (u32)o ? sh[threadIdx.x - o] : 0;
             __syncthreads();
-            sh[threadIdx.x] += a;
+            sh[threadIdx.x] = scan_op<OP>(sh[threadIdx.x], a);
             __syncthreads();
         }
         u64 incl = sh[threadIdx.x];
+        u64 excl = threadIdx.x ? sh[threadIdx.x - 1] : 0;
         u64 carry = carry_sh;
-        if (idx < ntiles) bsum[idx] = carry + incl - v;
+        if (idx < ntiles) bsum[idx] = scan_op<OP>(carry, excl);
         __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) carry_sh = carry + incl;
+        if (threadIdx.x == blockDim.x - 1) carry_sh = scan_op<OP>(carry, incl);
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = carry_sh;
 }
 
+template <int OP>
 static __global__ void k_scan_apply(const u64* __restrict__ in, u64* __restrict__ out,
                                     const u64* __restrict__ n_ptr, const u64* __restrict__ bsum)
 {
@@ -176,33 +185,42 @@ static __global__ void k_scan_apply(const u64* __restrict__ in, u64* __restrict_
         u64 s = 0;
         for (int i = 0; i < SCAN_ITEMS; i++) {
             v[i] = (base + i < n) ? in[base + i] : 0;
-            s += v[i];
+            s = scan_op<OP>(s, v[i]);
         }
         u64 incl = s;                                           // wave inclusive scan of s
         for (int o = 1; o < 64; o <<= 1) {
             u64 a = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += a;
+            if (lane >= o) incl = scan_op<OP>(incl, a);
         }
+        u64 excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0;
         if (lane == 63) wsum[w] = incl;
         __syncthreads();
         u64 woff = 0;
-        for (int i = 0; i < w; i++) woff += wsum[i];
-        u64 run = bsum[t] + woff + incl - s;
+        for (int i = 0; i < w; i++) woff = scan_op<OP>(woff, wsum[i]);
+        u64 run = scan_op<OP>(scan_op<OP>(bsum[t], woff), excl);   // everything before this thread's items
         for (int i = 0; i < SCAN_ITEMS; i++) {
-            if (base + i < n) out[base + i] = run;
-            run += v[i];
+            if (OP == 0) { if (base + i < n) out[base + i] = run; run += v[i]; }
+            else { run = scan_op<OP>(run, v[i]); if (base + i < n) out[base + i] = run; }
         }
         __syncthreads();
     }
 }
 
-// tmp must hold ceil(capacity / SCAN_TILE) u64
-inline void exclusive_scan_u64(const u64* in, u64* out, const u64* d_n, u64* d_total, u64* tmp,
-                               hipStream_t st)
+template <int OP>
+inline void device_scan_u64(const u64* in, u64* out, const u64* d_n, u64* d_total, u64* tmp, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1024), dim3(SCAN_THREADS), 0, st, in, d_n, tmp);
-    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, tmp, d_n, d_total);
-    hipLaunchKernelGGL(k_scan_apply, dim3(1024), dim3(SCAN_THREADS), 0, st, in, out, d_n, tmp);
+    hipLaunchKernelGGL((k_scan_tile_sums<OP>), dim3(1024), dim3(SCAN_THREADS), 0, st, in, d_n, tmp);
+    hipLaunchKernelGGL((k_scan_spine<OP>), dim3(1), dim3(1024), 0, st, tmp, d_n, d_total);
+    hipLaunchKernelGGL((k_scan_apply<OP>), dim3(1024), dim3(SCAN_THREADS), 0, st, in, out, d_n, tmp);
+}
+inline void exclusive_scan_u64(const u64* in, u64* out, const u64* d_n, u64* d_total, u64* tmp, hipStream_t st)
+{
+    device_scan_u64<0>(in, out, d_n, d_total, tmp, st);
+}
+inline void inclusive_max_scan_u64(const u64* in, u64* out, const u64* d_n, u64* d_total, u64* tmp, hipStream_t st)
+{
+    device_scan_u64<1>(in, out, d_n, d_total, tmp, st);
 }
 
 } // namespace edsx

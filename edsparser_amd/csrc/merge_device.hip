@@ -1,0 +1,489 @@
+// merge_device.hip — EDS -> l-EDS merge (LINEAR with sources / CARTESIAN) on gfx950.
+//
+// Replaces the reference's round loop (src/cpp/lib/transforms/eds_transforms.cpp):
+//   is_leds :439-468 + select_independent_merge_pairs :46-107  -> k_should, max-scan, k_select
+//   merge_multiple_pairs :120-196 -> EDS::merge_adjacent (eds.cpp:1425-1695) -> k_pair_count / k_pair_fill
+//   reconstruct_eds :207-296 (text round trip, an identity)            -> index compaction (scan)
+//   EDS::save / save_sources (eds.cpp:600-631, :641-659)               -> k_fin_* kernels
+// The reference rebuilds the whole container for every merged pair (quadratic); here a round
+// touches each symbol once and strings are materialised once, at the end.
+//
+// Data layout in HBM
+//   chars/str_off     all original strings back to back (host tokeniser, eds.cpp:39-155 rules)
+//   entry pool        one entry per string of every symbol that ever existed: leaves are the
+//                     original strings; an entry made by a merge points to its (left, right)
+//                     parents, carries its length and, for LINEAR, its source set as a bitset of
+//                     W 64-bit words (bit 0 = the universal path "0").  A symbol's entries are
+//                     contiguous in the pool, in the reference's product order (left outer).
+//   symbols           size[i], ent_off[i], len1[i] (length of the only string when size == 1)
+//                     for the current round, double buffered.
+#include "merge_device.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+
+namespace edsx {
+
+constexpr u32 LEAF = 0xffffffffu;
+constexpr u64 NO_ERR = ~0ull;
+
+struct SymArrays { u64* size; u64* ent_off; u64* len1; };
+struct Pool { u32* left; u32* right; u32* elen; u64* bits; u32 W; };
+
+// ---- per round -------------------------------------------------------------------------------
+// should[i] for the pair (i, i+1): eds_transforms.cpp:75-97
+__global__ void k_should(SymArrays s, u64 n, u64 l, u64* __restrict__ runmark, u64* __restrict__ any)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        bool sh = false;
+        if (i + 1 < n) {
+            const bool degA = s.size[i] > 1, degB = s.size[i + 1] > 1;
+            if (!degA && i > 0 && s.len1[i] < l) sh = true;
+            if (!degB && i + 1 < n - 1 && s.len1[i + 1] < l) sh = true;
+            if (degA && degB) sh = true;
+        }
+        // run mark for the max-scan: start of a run of consecutive `should` -> i+1, a gap -> 0 is
+        // not enough (a gap must cut the run), so gaps publish their own index with bit 63 set
+        u64 prev_sh = 0;
+        if (i > 0) {
+            const bool degP = s.size[i - 1] > 1, degA = s.size[i] > 1;
+            bool p = false;
+            if (!degP && i - 1 > 0 && s.len1[i - 1] < l) p = true;
+            if (!degA && i < n - 1 && s.len1[i] < l) p = true;
+            if (degP && degA) p = true;
+            prev_sh = p;
+        }
+        // value = 2*(position of the latest event)+kind, kind 1 = run start, 0 = gap; monotone in i
+        u64 v = 0;
+        if (!sh) v = 2 * (i + 1);
+        else if (!prev_sh) v = 2 * (i + 1) + 1;
+        runmark[i] = v;
+        if (sh) *any = 1;
+    }
+}
+
+// selected pairs: even offsets inside every run of consecutive `should` (:63-66, :99-103 greedy)
+__global__ void k_select(const u64* __restrict__ runscan, u64 n, u64* __restrict__ sel, u64* __restrict__ keep)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 v = runscan[i];
+        bool s = false;
+        if (v & 1) {                                   // inside a run that started at (v>>1)-1
+            const u64 start = (v >> 1) - 1;
+            s = ((i - start) & 1) == 0;
+        }
+        sel[i] = s;
+    }
+}
+__global__ void k_keep(const u64* __restrict__ sel, u64 n, u64* __restrict__ keep)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        keep[i] = !(i > 0 && sel[i - 1]);
+}
+
+// source-set intersection with the universal path 0 (eds.cpp:1481-1500); returns non-empty?
+__device__ __forceinline__ bool src_intersect(const u64* a, const u64* b, u32 W, u64* out)
+{
+    const bool ua = a[0] & 1, ub = b[0] & 1;
+    bool any = false;
+    for (u32 w = 0; w < W; w++) {
+        u64 v;
+        if (ua && ub) v = w == 0 ? 1ull : 0ull;
+        else if (ua) v = b[w];
+        else if (ub) v = a[w];
+        else v = a[w] & b[w];
+        if (out) out[w] = v;
+        any |= v != 0;
+    }
+    return any;
+}
+
+struct RoundParams {
+    SymArrays cur, nxt; Pool pool; u64 n; const u64* sel; const u64* keep; const u64* newidx;
+    u64* newcnt; const u64* newoff; u64 pool_used; u64* err_pos; u64* err_big; int linear;
+};
+
+// survivors of every selected pair (0 for symbols that are copied)
+__global__ void k_pair_count(RoundParams p)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < p.n; i += (u64)gridDim.x * blockDim.x) {
+        if (!p.keep[i]) continue;
+        u64 cnt = 0;
+        if (p.sel[i]) {
+            const u64 na = p.cur.size[i], nb = p.cur.size[i + 1];
+            if (!p.linear) {
+                if (na != 0 && nb > 0xffffffffull / na) { atomicMin(p.err_big, i); cnt = 0; }
+                else cnt = na * nb;
+            } else {
+                const u64 a0 = p.cur.ent_off[i], b0 = p.cur.ent_off[i + 1];
+                for (u64 x = 0; x < na; x++)
+                    for (u64 y = 0; y < nb; y++)
+                        cnt += src_intersect(p.pool.bits + (a0 + x) * p.pool.W, p.pool.bits + (b0 + y) * p.pool.W,
+                                             p.pool.W, nullptr);
+                if (cnt == 0) atomicMin(p.err_pos, i);           // eds.cpp:1513-1519
+            }
+        }
+        p.newcnt[p.newidx[i]] = cnt;
+    }
+}
+
+// new symbol list + the entries of the merged symbols (product order: left outer, right inner)
+__global__ void k_pair_fill(RoundParams p)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < p.n; i += (u64)gridDim.x * blockDim.x) {
+        if (!p.keep[i]) continue;
+        const u64 j = p.newidx[i];
+        if (!p.sel[i]) {
+            p.nxt.size[j] = p.cur.size[i]; p.nxt.ent_off[j] = p.cur.ent_off[i]; p.nxt.len1[j] = p.cur.len1[i];
+            continue;
+        }
+        const u64 na = p.cur.size[i], nb = p.cur.size[i + 1];
+        const u64 a0 = p.cur.ent_off[i], b0 = p.cur.ent_off[i + 1];
+        u64 o = p.pool_used + p.newoff[j];
+        const u64 first = o;
+        for (u64 x = 0; x < na; x++)
+            for (u64 y = 0; y < nb; y++) {
+                if (p.linear) {
+                    const u64* sa = p.pool.bits + (a0 + x) * p.pool.W;
+                    const u64* sb = p.pool.bits + (b0 + y) * p.pool.W;
+                    // test first: slot o belongs to the next symbol once this one's survivors are written
+                    if (!src_intersect(sa, sb, p.pool.W, nullptr)) continue;
+                    src_intersect(sa, sb, p.pool.W, p.pool.bits + o * p.pool.W);
+                }
+                p.pool.left[o] = (u32)(a0 + x);
+                p.pool.right[o] = (u32)(b0 + y);
+                p.pool.elen[o] = p.pool.elen[a0 + x] + p.pool.elen[b0 + y];
+                o++;
+            }
+        const u64 cnt = o - first;
+        p.nxt.size[j] = cnt; p.nxt.ent_off[j] = first; p.nxt.len1[j] = cnt == 1 ? p.pool.elen[first] : 0;
+    }
+}
+
+// ---- final text --------------------------------------------------------------------------------
+struct FinParams {
+    SymArrays sym; Pool pool; u64 n; const u64* cum;     // cum = exclusive scan of sym.size
+    u32* fin_ent; uint8_t* fin_flag;                      // per final string: entry, 1 = first | 2 = last | 4 = brackets
+    u64* bytes; u64* sbytes;                              // per final string: eds bytes / seds bytes (-> offsets)
+    const uint8_t* chars; const u64* str_off;
+    uint8_t* out; uint8_t* sout; u64* err; int compact, linear;
+};
+
+__global__ void k_fin_list(FinParams p)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < p.n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 k = p.sym.size[i], e0 = p.sym.ent_off[i], t0 = p.cum[i];
+        const bool br = !p.compact || k > 1;                   // eds.cpp:613
+        for (u64 x = 0; x < k; x++) {
+            const u64 t = t0 + x;
+            p.fin_ent[t] = (u32)(e0 + x);
+            uint8_t fl = (x == 0 ? 1 : 0) | (x + 1 == k ? 2 : 0) | (br ? 4 : 0);
+            p.fin_flag[t] = fl;
+            p.bytes[t] = (u64)p.pool.elen[e0 + x] + ((x == 0) ? (br ? 1 : 0) : 1) + ((x + 1 == k && br) ? 1 : 0);
+            if (p.linear) {
+                const u64* b = p.pool.bits + (e0 + x) * p.pool.W;
+                u64 sb = 1;                                    // '{' ; every id is followed by ',' or '}'
+                for (u32 w = 0; w < p.pool.W; w++) {
+                    u64 v = b[w];
+                    while (v) { u32 id = w * 64 + __builtin_ctzll(v); v &= v - 1; sb += ndigits(id ? id : 1) + 1; }
+                }
+                p.sbytes[t] = sb;
+            }
+        }
+    }
+}
+
+// one thread per final string: walk the entry tree left to right and copy the leaf strings
+__global__ void k_fin_write(FinParams p, u64 nstr)
+{
+    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < nstr; t += (u64)gridDim.x * blockDim.x) {
+        const uint8_t fl = p.fin_flag[t];
+        uint8_t* o = p.out + p.bytes[t];
+        {   // opening bracket of the symbol's first string, else the separator (kept branch-free:
+            // hipcc 7.2 lost the pointer increment when this was written as nested ifs)
+            const bool first = (fl & 1) != 0, wr = !first || (fl & 4) != 0;
+            if (wr) *o = first ? '{' : ',';
+            o += wr ? 1 : 0;
+        }
+        u32 stack[96];
+        int sp = 0;
+        stack[sp++] = p.fin_ent[t];
+        while (sp) {
+            const u32 e = stack[--sp];
+            if (p.pool.left[e] == LEAF) {
+                const u64 s0 = p.str_off[p.pool.right[e]], s1 = p.str_off[p.pool.right[e] + 1];
+                for (u64 c = s0; c < s1; c++) *o++ = p.chars[c];
+            } else {
+                if (sp + 2 > 96) { *p.err = 1; break; }
+                stack[sp++] = p.pool.right[e];
+                stack[sp++] = p.pool.left[e];
+            }
+        }
+        if ((fl & 2) && (fl & 4)) *o++ = '}';
+        if (p.linear) {
+            uint8_t* so = p.sout + p.sbytes[t];
+            *so++ = '{';
+            const u64* b = p.pool.bits + (u64)p.fin_ent[t] * p.pool.W;
+            for (u32 w = 0; w < p.pool.W; w++) {
+                u64 v = b[w];
+                while (v) {
+                    u32 id = w * 64 + __builtin_ctzll(v);
+                    v &= v - 1;
+                    u32 nd = ndigits(id ? id : 1);
+                    u32 x = id;
+                    for (int d = (int)nd - 1; d >= 0; d--) { so[d] = (uint8_t)('0' + x % 10); x /= 10; }
+                    so += nd;
+                    *so++ = ',';
+                }
+            }
+            so[-1] = '}';
+        }
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------
+namespace {
+
+std::string strip_ws(const uint8_t* p, size_t n)
+{
+    std::string s;
+    s.reserve(n);
+    for (size_t i = 0; i < n; i++) if (!std::isspace(p[i])) s.push_back((char)p[i]);
+    return s;
+}
+
+std::string normalize(const std::string& in)                 // eds.cpp:831-881
+{
+    std::string out, run;
+    out.reserve(in.size() + 16);
+    int depth = 0;
+    for (char ch : in) {
+        if (ch == '{') {
+            if (!run.empty() && depth == 0) { out += '{'; out += run; out += '}'; run.clear(); }
+            out += ch; depth++;
+        } else if (ch == '}') { out += ch; depth--; }
+        else if (depth > 0) out += ch;
+        else run += ch;
+    }
+    if (!run.empty() && depth == 0) { out += '{'; out += run; out += '}'; }
+    return out;
+}
+
+void grow_keep(DevBuf& b, size_t used, size_t need, hipStream_t st)
+{
+    if (need <= b.cap) return;
+    DevBuf nb;
+    nb.ensure(std::max(need, b.cap * 2));
+    if (used) EDSX_HIP(hipMemcpyAsync(nb.ptr, b.ptr, used, hipMemcpyDeviceToDevice, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    std::swap(b.ptr, nb.ptr);
+    std::swap(b.cap, nb.cap);
+}
+
+} // namespace
+
+void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l, bool compact,
+                        std::string& out, std::string& seds_out, hipStream_t st)
+{
+    if (l == 0) throw ParamError("context_length must be > 0 for l-EDS transformation");   // :322-324
+    const bool linear = seds != nullptr;
+
+    // ---- host tokeniser: eds.cpp:39-155 (same error texts)
+    std::vector<uint8_t> chars;
+    std::vector<u64> str_off{0}, sym_first{0};
+    {
+        std::string in = strip_ws(eds, eds_n);
+        if (!in.empty()) {
+            in = normalize(in);
+            chars.reserve(in.size());
+            size_t pos = 0;
+            while (pos < in.size()) {
+                if (in[pos] != '{') throw FormatError("Expected '{' at position " + std::to_string(pos));
+                pos++;
+                while (pos < in.size() && in[pos] != '}') {
+                    if (in[pos] == ',') str_off.push_back(chars.size());
+                    else chars.push_back((uint8_t)in[pos]);
+                    pos++;
+                }
+                str_off.push_back(chars.size());
+                if (pos >= in.size() || in[pos] != '}') throw FormatError("Expected '}' at position " + std::to_string(pos));
+                pos++;
+                sym_first.push_back(str_off.size() - 1);
+            }
+        }
+    }
+    const u64 n0 = sym_first.size() - 1, m = str_off.size() - 1;
+
+    // ---- sources: eds.cpp:268-355 -> bitsets
+    u32 W = 1;
+    std::vector<u64> bits;
+    if (linear) {
+        std::string in = strip_ws(seds, seds_n);
+        if (in.empty()) throw FormatError("sEDS input is empty");
+        std::vector<std::vector<int>> sets;
+        int maxid = 0;
+        size_t pos = 0;
+        while (pos < in.size()) {
+            if (in[pos] != '{') throw FormatError("sEDS: Expected '{' at position " + std::to_string(pos));
+            pos++;
+            std::vector<int> ids;
+            std::string num;
+            auto flush = [&] {
+                if (num.empty()) return;
+                int id;
+                try { id = std::stoi(num); } catch (...) { throw FormatError("stoi"); }
+                ids.push_back(id);
+                maxid = std::max(maxid, id);
+                num.clear();
+            };
+            while (pos < in.size() && in[pos] != '}') {
+                if (in[pos] == ',') flush();
+                else if (std::isdigit((unsigned char)in[pos])) num += in[pos];
+                else
+                    throw FormatError("sEDS: Invalid character '" + std::string(1, in[pos]) + "' at position " +
+                                      std::to_string(pos));
+                pos++;
+            }
+            flush();
+            if (pos >= in.size() || in[pos] != '}') throw FormatError("sEDS: Expected '}' at position " + std::to_string(pos));
+            pos++;
+            if (ids.empty()) throw FormatError("sEDS: Empty path set at string " + std::to_string(sets.size()));
+            sets.push_back(std::move(ids));
+        }
+        if (sets.size() != m)
+            throw FormatError("sEDS: Source count (" + std::to_string(sets.size()) + ") does not match EDS cardinality (" +
+                              std::to_string(m) + ")");
+        W = (u32)(maxid / 64 + 1);
+        bits.assign((size_t)m * W, 0);
+        for (size_t sidx = 0; sidx < m; sidx++)
+            for (int id : sets[sidx]) bits[sidx * W + id / 64] |= 1ull << (id % 64);
+    }
+
+    if (n0 == 0) {                                           // empty EDS: save() prints "\n" (quirk 19)
+        out = "\n";
+        seds_out.clear();
+        return;
+    }
+    if (m >= 0xfffffff0ull) throw FormatError("EDS has too many strings for this build");
+
+    // ---- upload
+    d_chars_.ensure(chars.size() + 16);
+    d_str_off_.ensure(8 * (m + 1));
+    EDSX_HIP(hipMemcpyAsync(d_chars_.ptr, chars.data(), chars.size(), hipMemcpyHostToDevice, st));
+    EDSX_HIP(hipMemcpyAsync(d_str_off_.ptr, str_off.data(), 8 * (m + 1), hipMemcpyHostToDevice, st));
+    size_t pool_cap = std::max<size_t>(2 * m + 1024, 4096);
+    left_.ensure(4 * pool_cap); right_.ensure(4 * pool_cap); elen_.ensure(4 * pool_cap);
+    if (linear) bits_.ensure(8 * pool_cap * W);
+    {
+        std::vector<u32> hl(m, LEAF), hr(m), he(m);
+        for (u64 s = 0; s < m; s++) { hr[s] = (u32)s; he[s] = (u32)(str_off[s + 1] - str_off[s]); }
+        EDSX_HIP(hipMemcpyAsync(left_.ptr, hl.data(), 4 * m, hipMemcpyHostToDevice, st));
+        EDSX_HIP(hipMemcpyAsync(right_.ptr, hr.data(), 4 * m, hipMemcpyHostToDevice, st));
+        EDSX_HIP(hipMemcpyAsync(elen_.ptr, he.data(), 4 * m, hipMemcpyHostToDevice, st));
+        if (linear) EDSX_HIP(hipMemcpyAsync(bits_.ptr, bits.data(), 8 * (size_t)m * W, hipMemcpyHostToDevice, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+    }
+    for (int b = 0; b < 2; b++) { size_[b].ensure(8 * (n0 + 1)); ent_off_[b].ensure(8 * (n0 + 1)); len1_[b].ensure(8 * (n0 + 1)); }
+    {
+        std::vector<u64> hs(n0), ho(n0), hl(n0);
+        for (u64 i = 0; i < n0; i++) {
+            hs[i] = sym_first[i + 1] - sym_first[i];
+            ho[i] = sym_first[i];
+            hl[i] = hs[i] == 1 ? str_off[sym_first[i] + 1] - str_off[sym_first[i]] : 0;
+        }
+        EDSX_HIP(hipMemcpyAsync(size_[0].ptr, hs.data(), 8 * n0, hipMemcpyHostToDevice, st));
+        EDSX_HIP(hipMemcpyAsync(ent_off_[0].ptr, ho.data(), 8 * n0, hipMemcpyHostToDevice, st));
+        EDSX_HIP(hipMemcpyAsync(len1_[0].ptr, hl.data(), 8 * n0, hipMemcpyHostToDevice, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+    }
+    a_.ensure(8 * (n0 + 2)); b_.ensure(8 * (n0 + 2)); c_.ensure(8 * (n0 + 2)); d_.ensure(8 * (n0 + 2)); e_.ensure(8 * (n0 + 2));
+    scan_tmp_.ensure(8 * ((n0 + 2) / SCAN_TILE + 2));
+    ctl_.ensure(8 * 16);
+    u64* ctl = ctl_.as<u64>();         // [0]=n  [1]=any  [2]=n_new  [3]=total_new  [4]=err_pos  [5]=err_big  [6]=scratch
+
+    u64 n = n0, pool_used = m;
+    int cur = 0;
+    size_t iteration = 0;
+    const size_t MAX_ITERATIONS = 10000;                     // eds_transforms.cpp:335
+    while (iteration < MAX_ITERATIONS) {
+        if (n < 2) break;
+        u64 hctl[8] = {n, 0, 0, 0, NO_ERR, NO_ERR, 0, 0};
+        EDSX_HIP(hipMemcpyAsync(ctl, hctl, sizeof(hctl), hipMemcpyHostToDevice, st));
+        SymArrays sc{size_[cur].as<u64>(), ent_off_[cur].as<u64>(), len1_[cur].as<u64>()};
+        SymArrays sn{size_[cur ^ 1].as<u64>(), ent_off_[cur ^ 1].as<u64>(), len1_[cur ^ 1].as<u64>()};
+        Pool pool{left_.as<u32>(), right_.as<u32>(), elen_.as<u32>(), bits_.as<u64>(), W};
+        u64 *runmark = a_.as<u64>(), *sel = b_.as<u64>(), *keep = c_.as<u64>(), *newidx = d_.as<u64>(), *newcnt = e_.as<u64>();
+        hipLaunchKernelGGL(k_should, dim3(1024), dim3(256), 0, st, sc, n, (u64)l, runmark, ctl + 1);
+        inclusive_max_scan_u64(runmark, runmark, ctl + 0, ctl + 6, scan_tmp_.as<u64>(), st);
+        hipLaunchKernelGGL(k_select, dim3(1024), dim3(256), 0, st, runmark, n, sel, keep);
+        hipLaunchKernelGGL(k_keep, dim3(1024), dim3(256), 0, st, sel, n, keep);
+        exclusive_scan_u64(keep, newidx, ctl + 0, ctl + 2, scan_tmp_.as<u64>(), st);
+        RoundParams rp{sc, sn, pool, n, sel, keep, newidx, newcnt, newcnt, pool_used, ctl + 4, ctl + 5, linear ? 1 : 0};
+        hipLaunchKernelGGL(k_pair_count, dim3(1024), dim3(256), 0, st, rp);
+        exclusive_scan_u64(newcnt, newcnt, ctl + 2, ctl + 3, scan_tmp_.as<u64>(), st);
+        EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        if (!hctl[1]) break;                                 // is_leds: nothing left to merge
+        if (hctl[4] != NO_ERR)
+            throw FormatError("Merging positions " + std::to_string(hctl[4]) + " and " + std::to_string(hctl[4] + 1) +
+                              " results in empty set (no valid source intersections)");
+        if (hctl[5] != NO_ERR || pool_used + hctl[3] >= 0xfffffff0ull)
+            throw FormatError("l-EDS merge produces more than 2^32 strings; refusing (the reference would exhaust memory)");
+        const u64 n_new = hctl[2], total_new = hctl[3];
+        const size_t need = pool_used + total_new + 16;
+        grow_keep(left_, 4 * pool_used, 4 * need, st);
+        grow_keep(right_, 4 * pool_used, 4 * need, st);
+        grow_keep(elen_, 4 * pool_used, 4 * need, st);
+        if (linear) grow_keep(bits_, 8 * pool_used * W, 8 * need * W, st);
+        rp.pool = Pool{left_.as<u32>(), right_.as<u32>(), elen_.as<u32>(), bits_.as<u64>(), W};
+        hipLaunchKernelGGL(k_pair_fill, dim3(1024), dim3(256), 0, st, rp);
+        pool_used += total_new;
+        n = n_new;
+        cur ^= 1;
+        iteration++;
+    }
+    if (iteration >= MAX_ITERATIONS) throw FormatError("Maximum iterations reached without convergence");
+
+    // ---- final text
+    SymArrays sf{size_[cur].as<u64>(), ent_off_[cur].as<u64>(), len1_[cur].as<u64>()};
+    Pool pool{left_.as<u32>(), right_.as<u32>(), elen_.as<u32>(), bits_.as<u64>(), W};
+    u64 hctl[8] = {n, 0, 0, 0, 0, 0, 0, 0};
+    EDSX_HIP(hipMemcpyAsync(ctl, hctl, sizeof(hctl), hipMemcpyHostToDevice, st));
+    u64* cum = a_.as<u64>();
+    exclusive_scan_u64(sf.size, cum, ctl + 0, ctl + 1, scan_tmp_.as<u64>(), st);
+    EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    const u64 nstr = hctl[1];
+    if (nstr >= 0xfffffff0ull) throw FormatError("l-EDS output has too many strings");
+    fin_ent_.ensure(4 * (nstr + 1)); fin_flag_.ensure(nstr + 16); fbytes_.ensure(8 * (nstr + 2)); fsbytes_.ensure(8 * (nstr + 2));
+    scan_tmp_.ensure(8 * ((nstr + 2) / SCAN_TILE + 2));
+    FinParams fp{sf, pool, n, cum, fin_ent_.as<u32>(), fin_flag_.as<uint8_t>(), fbytes_.as<u64>(), fsbytes_.as<u64>(),
+                 d_chars_.as<uint8_t>(), d_str_off_.as<u64>(), nullptr, nullptr, ctl + 4, compact ? 1 : 0, linear ? 1 : 0};
+    hipLaunchKernelGGL(k_fin_list, dim3(1024), dim3(256), 0, st, fp);
+    hctl[0] = nstr; hctl[4] = 0;
+    EDSX_HIP(hipMemcpyAsync(ctl, hctl, sizeof(hctl), hipMemcpyHostToDevice, st));
+    exclusive_scan_u64(fbytes_.as<u64>(), fbytes_.as<u64>(), ctl + 0, ctl + 2, scan_tmp_.as<u64>(), st);
+    if (linear) exclusive_scan_u64(fsbytes_.as<u64>(), fsbytes_.as<u64>(), ctl + 0, ctl + 3, scan_tmp_.as<u64>(), st);
+    EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    const u64 E = hctl[2], Q = linear ? hctl[3] : 0;
+    d_out_.ensure(E + 16);
+    if (linear) d_sout_.ensure(Q + 16);
+    fp.out = d_out_.as<uint8_t>(); fp.sout = d_sout_.as<uint8_t>();
+    hipLaunchKernelGGL(k_fin_write, dim3(2048), dim3(256), 0, st, fp, nstr);
+    out.resize(E + 1);
+    EDSX_HIP(hipMemcpyAsync(&out[0], d_out_.ptr, E, hipMemcpyDeviceToHost, st));
+    if (linear) {
+        seds_out.resize(Q + 1);
+        EDSX_HIP(hipMemcpyAsync(&seds_out[0], d_sout_.ptr, Q, hipMemcpyDeviceToHost, st));
+    } else seds_out.clear();
+    EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    EDSX_HIP(hipGetLastError());
+    if (hctl[4]) throw FormatError("l-EDS merge nesting deeper than this build supports");
+    out[E] = '\n';                                           // eds.cpp:630
+    if (linear) seds_out[Q] = '\n';                          // eds.cpp:658
+}
+
+} // namespace edsx
