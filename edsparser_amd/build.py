@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libedsx.so")
-SOURCES = ["msa_device.hip", "merge_device.hip", "synth.hip", "capi.hip"]
-HEADERS = ["dev_util.hpp", "msa_device.hpp", "merge_device.hpp", "synth.hpp", os.path.join("..", "..", "include", "edsx.h")]
+SOURCES = ["msa_device.hip", "merge_device.hip", "vcf_device.hip", "synth.hip", "capi.hip"]
+HEADERS = ["dev_util.hpp", "msa_device.hpp", "merge_device.hpp", "vcf_device.hpp", "synth.hpp", os.path.join("..", "..", "include", "edsx.h")]
 
 
 def _stale():

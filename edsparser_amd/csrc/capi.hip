@@ -4,6 +4,7 @@
 #include "merge_device.hpp"
 #include "msa_device.hpp"
 #include "synth.hpp"
+#include "vcf_device.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +18,7 @@ struct edsx_ctx {
     std::string err;
     MsaPipeline msa;
     MergePipeline merge;
+    VcfPipeline vcf;
     DevBuf d_in, d_eds, d_seds, synth_desc;
 };
 
@@ -159,12 +161,43 @@ int edsx_leds_merge(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const ui
     });
 }
 
-int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t*, size_t, const uint8_t*, size_t, uint32_t,
-                       edsx_buf* eds, edsx_buf* seds, edsx_vcf_stats*)
+int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, const uint8_t* fasta, size_t fasta_size,
+                       uint32_t context_len, edsx_buf* eds, edsx_buf* seds, edsx_vcf_stats* stats)
 {
     if (eds) { eds->data = nullptr; eds->size = 0; }
     if (seds) { seds->data = nullptr; seds->size = 0; }
-    return guarded(ctx, [&] { throw DeviceError("edsx_vcf_transform: device path not built yet"); });
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    return guarded(ctx, [&] {
+        if (!eds || !seds || (!vcf && vcf_size) || (!fasta && fasta_size)) throw ParamError("null argument");
+        static const uint8_t none = 0;
+        std::string e, s;
+        VcfCounters c;
+        try {
+            ctx->vcf.run(vcf ? vcf : &none, vcf_size, fasta ? fasta : &none, fasta_size, e, s, c, nullptr);
+        } catch (...) {
+            if (stats) {   // the reference counts while parsing, before it can throw
+                stats->total_variants = c.total_variants; stats->processed_variants = c.processed_variants;
+                stats->skipped_malformed = c.skipped_malformed; stats->skipped_unsupported_sv = c.skipped_unsupported_sv;
+            }
+            throw;
+        }
+        if (stats) {
+            stats->total_variants = c.total_variants; stats->processed_variants = c.processed_variants;
+            stats->skipped_malformed = c.skipped_malformed; stats->skipped_unsupported_sv = c.skipped_unsupported_sv;
+            stats->variant_groups = c.variant_groups;
+        }
+        if (context_len > 0) {   // vcf_transforms.cpp:735-755: EDS text -> LINEAR merge with defaults (compact)
+            std::string lo, so;
+            ctx->merge.run(reinterpret_cast<const uint8_t*>(e.data()), e.size(), reinterpret_cast<const uint8_t*>(s.data()),
+                           s.size(), context_len, true, lo, so, nullptr);
+            e.swap(lo);
+            s.swap(so);
+        }
+        take(eds, e.size());
+        std::memcpy(eds->data, e.data(), e.size());
+        take(seds, s.size());
+        std::memcpy(seds->data, s.data(), s.size());
+    });
 }
 
 size_t edsx_msa_synth_size(uint32_t n_rows, uint64_t n_cols) { return synth_size(n_rows, n_cols); }

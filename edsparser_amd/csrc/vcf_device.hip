@@ -1,0 +1,644 @@
+// vcf_device.hip — VCF (+ reference FASTA) -> EDS / sEDS on gfx950: the variant-overlay walk.
+//
+// Host (this file, C++): FASTA metadata, VCF tokeniser, std::sort by POS — the text-parsing front
+// end of src/cpp/lib/transforms/vcf_transforms.cpp (:51-86, :142-326, :715-718).
+// Device (HIP kernels): everything from the sorted records on —
+//   group_overlapping_variants :482-534   -> max-scan of the record ends + k_mark_groups
+//   read_fasta_region :98-129             -> k_fa_count/k_fa_compact (newline-free reference stream)
+//   merge_variant_group :396-476          -> k_grp_count / k_grp_haps / k_grp_samples
+//   generate_eds_from_variants :554-668   -> k_grp_sizes / k_grp_emit
+//
+// Data layout in HBM
+//   refc            the FASTA bytes from the first sequence line to EOF with '\n' and '\r' removed
+//                   (exactly the characters read_fasta_region can return), blkpre[] = kept bytes
+//                   before every 256-byte block, so any file offset maps to a position in refc.
+//   records (SoA)   start (0-based), reflen, alt range -> alt strings, per (record, sample) allele
+//                   lists (two-level CSR), all in sorted order.
+//   groups          first record, span [gs, gs+spanlen) in refc, raw haplotypes materialised once in
+//                   hapchars, canonical (deduplicated) index per raw haplotype, carried[hap][sample]
+//                   bit matrix.
+#include "vcf_device.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <sstream>
+
+namespace edsx {
+
+struct VcfDev {
+    // reference
+    const uint8_t* fasta; u64 fasta_n; u64 seq_start, seq_size, lw;
+    const uint8_t* refc; u64 refc_n; const u64* blkpre;
+    // records
+    u64 nrec; const u64* start; const u64* reflen; const u64* alt0; const u64* altstr_off; const uint8_t* altchars;
+    const u64* pair0;          // per record: first (record,sample) pair; pair0[nrec] = #pairs
+    const u64* pair_a0;        // per pair: first allele; pair_a0[#pairs] = #alleles
+    const int* alleles;
+    // groups
+    u64 ngrp; const u64* grp_r0;   // first record of group g, grp_r0[ngrp] = nrec
+    const u64* incl_end;           // inclusive max-scan of record ends
+};
+
+__device__ __forceinline__ u64 fa_cpos(const VcfDev& d, u64 file_off)
+{   // position in refc of file offset file_off (>= seq_start); offsets past EOF map to refc_n
+    if (file_off >= d.fasta_n) return d.refc_n;
+    const u64 rel = file_off - d.seq_start;
+    u64 c = d.blkpre[rel >> 8];
+    for (u64 f = d.seq_start + (rel & ~255ull); f < file_off; f++) {
+        const uint8_t ch = d.fasta[f];
+        c += (ch != '\n' && ch != '\r');
+    }
+    return c;
+}
+
+// ---- reference stream ---------------------------------------------------------------------------
+__global__ void k_fa_count(const uint8_t* __restrict__ f, u64 n, u64 seq_start, u64* __restrict__ blkcnt, u64 nblk)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 b = wave; b < nblk; b += nw) {
+        const u64 base = seq_start + b * 256 + lane * 4;
+        u32 c = 0;
+        for (int i = 0; i < 4; i++) if (base + i < n) { uint8_t ch = f[base + i]; c += (ch != '\n' && ch != '\r'); }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if (lane == 0) blkcnt[b] = c;
+    }
+}
+__global__ void k_fa_compact(const uint8_t* __restrict__ f, u64 n, u64 seq_start, const u64* __restrict__ blkpre,
+                             u64 nblk, uint8_t* __restrict__ refc)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 b = wave; b < nblk; b += nw) {
+        const u64 base = seq_start + b * 256 + lane * 4;
+        uint8_t ch[4];
+        u32 c = 0;
+        for (int i = 0; i < 4; i++) {
+            ch[i] = base + i < n ? f[base + i] : (uint8_t)'\n';
+            c += (ch[i] != '\n' && ch[i] != '\r');
+        }
+        u32 incl = c;
+        for (int o = 1; o < 64; o <<= 1) { u32 a = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += a; }
+        u64 o = blkpre[b] + incl - c;
+        for (int i = 0; i < 4; i++) if (ch[i] != '\n' && ch[i] != '\r') refc[o++] = ch[i];
+    }
+}
+
+// ---- grouping -------------------------------------------------------------------------------------
+__global__ void k_rec_ends(const u64* __restrict__ start, const u64* __restrict__ reflen, u64 n, u64* __restrict__ ends)
+{
+    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < n; j += (u64)gridDim.x * blockDim.x)
+        ends[j] = start[j] + reflen[j];
+}
+// a record opens a group iff its start is not below the largest end seen before it (:510)
+__global__ void k_mark_groups(const u64* __restrict__ start, const u64* __restrict__ incl_end, u64 n, u64* __restrict__ flag)
+{
+    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < n; j += (u64)gridDim.x * blockDim.x)
+        flag[j] = (j == 0) || !(start[j] < incl_end[j - 1]);
+}
+__global__ void k_group_firsts(const u64* __restrict__ flag, const u64* __restrict__ gidx, u64 n, u64* __restrict__ grp_r0,
+                               const u64* __restrict__ ngrp)
+{
+    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < n; j += (u64)gridDim.x * blockDim.x)
+        if (flag[j]) grp_r0[gidx[j]] = j;
+    if (blockIdx.x == 0 && threadIdx.x == 0) grp_r0[*ngrp] = n;
+}
+
+// ---- per group: thread per group ---------------------------------------------------------------------
+struct GrpArrays {
+    u64* gs; u64* spanlen; u64* cs;          // span start (sequence position), clamped length, refc position
+    u64* nraw; u64* rawchars;                // raw haplotypes (1 + sum of alts) and their total length
+    u64* ndist;                              // distinct haplotypes
+    u64* bitwords;                           // ndist * sample words
+    u64* eds_len; u64* seds_len;             // group symbol + preceding common region
+    u64* commonlen; u64* cur_after;          // common region before the group, reference position after it
+    u64* err;                                // [0] first failing group, [1] offset, [2] span length
+};
+
+__device__ __forceinline__ u64 hap_len(u64 off, u64 altlen, u64 reflen, u64 spanlen)
+{
+    u64 len = off + altlen;
+    if (off + reflen < spanlen) len += spanlen - (off + reflen);
+    return len;
+}
+
+__global__ void k_grp_count(VcfDev d, GrpArrays a)
+{
+    for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < d.ngrp; g += (u64)gridDim.x * blockDim.x) {
+        const u64 r0 = d.grp_r0[g], r1 = d.grp_r0[g + 1];
+        const u64 gs = d.start[r0], ge = d.incl_end[r1 - 1];
+        u64 spanlen = 0, cs = d.refc_n;
+        if (gs < d.seq_size) {                                 // read_fasta_region :102-109
+            u64 length = ge - gs;
+            if (gs + length > d.seq_size) length = d.seq_size - gs;
+            cs = fa_cpos(d, d.seq_start + gs + gs / d.lw);
+            spanlen = length < d.refc_n - cs ? length : d.refc_n - cs;
+        }
+        a.gs[g] = gs; a.spanlen[g] = spanlen; a.cs[g] = cs;
+        u64 nraw = 1, chars = spanlen;
+        for (u64 v = r0; v < r1; v++) {
+            const u64 off = d.start[v] - gs;
+            const u64 nalt = d.alt0[v + 1] - d.alt0[v];
+            if (off > spanlen && nalt) {                       // span.substr(0, off) throws (:375)
+                if (atomicMin(&a.err[0], g) > g) { /* recorded below by the winning group */ }
+                break;
+            }
+            for (u64 x = d.alt0[v]; x < d.alt0[v + 1]; x++)
+                chars += hap_len(off, d.altstr_off[x + 1] - d.altstr_off[x], d.reflen[v], spanlen);
+            nraw += nalt;
+        }
+        a.nraw[g] = nraw; a.rawchars[g] = chars;
+    }
+}
+
+struct HapArrays {
+    const u64* raw0; const u64* rawc0;       // exclusive scans of nraw / rawchars
+    u64* rawlen; u64* rawoff; u32* canon;    // per raw haplotype: length, offset in hapchars, canonical index
+    uint8_t* hapchars;
+    const u64* bit0;                         // exclusive scan of bitwords
+    u64* carried;                            // bit matrix [canonical hap][sample word]
+    u32 sw;                                  // sample words = ceil(max_samples / 64)
+};
+
+// materialise the raw haplotypes (span first, then every ALT applied alone: :416-435) and
+// deduplicate them keeping the first occurrence
+__global__ void k_grp_haps(VcfDev d, GrpArrays a, HapArrays h)
+{
+    for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < d.ngrp; g += (u64)gridDim.x * blockDim.x) {
+        const u64 r0 = d.grp_r0[g], r1 = d.grp_r0[g + 1];
+        const u64 gs = a.gs[g], spanlen = a.spanlen[g], cs = a.cs[g];
+        const uint8_t* span = d.refc + cs;
+        u64 hi = h.raw0[g];
+        u64 co = h.rawc0[g];
+        // raw hap 0 = the reference span
+        h.rawlen[hi] = spanlen; h.rawoff[hi] = co;
+        for (u64 i = 0; i < spanlen; i++) h.hapchars[co + i] = span[i];
+        co += spanlen; hi++;
+        const u64 nraw = a.nraw[g];
+        for (u64 v = r0; v < r1 && hi < h.raw0[g] + nraw; v++) {
+            const u64 off = d.start[v] - gs, rl = d.reflen[v];
+            for (u64 x = d.alt0[v]; x < d.alt0[v + 1]; x++) {
+                const u64 al = d.altstr_off[x + 1] - d.altstr_off[x];
+                const u64 len = hap_len(off, al, rl, spanlen);
+                h.rawlen[hi] = len; h.rawoff[hi] = co;
+                uint8_t* dst = h.hapchars + co;
+                for (u64 i = 0; i < off; i++) *dst++ = span[i];
+                for (u64 i = 0; i < al; i++) *dst++ = d.altchars[d.altstr_off[x] + i];
+                if (off + rl < spanlen) for (u64 i = off + rl; i < spanlen; i++) *dst++ = span[i];
+                co += len; hi++;
+            }
+        }
+        // dedup, first occurrence wins
+        const u64 h0 = h.raw0[g];
+        u32 nd = 0;
+        for (u64 x = 0; x < nraw; x++) {
+            u32 c = 0xffffffffu;
+            for (u64 y = 0; y < x; y++) {
+                if (h.rawlen[h0 + y] != h.rawlen[h0 + x] || h.canon[h0 + y] & 0x80000000u) continue;
+                const uint8_t* p = h.hapchars + h.rawoff[h0 + x];
+                const uint8_t* q = h.hapchars + h.rawoff[h0 + y];
+                bool eq = true;
+                for (u64 i = 0; i < h.rawlen[h0 + x]; i++) if (p[i] != q[i]) { eq = false; break; }
+                if (eq) { c = h.canon[h0 + y]; break; }
+            }
+            // bit 31 marks "duplicate of an earlier one" so that only first occurrences are compared against
+            h.canon[h0 + x] = c == 0xffffffffu ? nd++ : (c | 0x80000000u);
+        }
+        a.ndist[g] = nd;
+        a.bitwords[g] = (u64)nd * h.sw;
+    }
+}
+
+// which samples carry which haplotype (:438-473) and the text sizes (:570-651)
+__global__ void k_grp_samples(VcfDev d, GrpArrays a, HapArrays h)
+{
+    for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < d.ngrp; g += (u64)gridDim.x * blockDim.x) {
+        const u64 r0 = d.grp_r0[g], r1 = d.grp_r0[g + 1];
+        const u64 h0 = h.raw0[g];
+        const u64 nd = a.ndist[g];
+        u64* bits = h.carried + h.bit0[g];
+        for (u64 i = 0; i < nd * h.sw; i++) bits[i] = 0;
+        const u64 nsamp = d.pair0[r0 + 1] - d.pair0[r0];       // samples of the group's first record (:407)
+        for (u64 s = 0; s < nsamp; s++) {
+            bool any = false;
+            u64 rawbase = 1;
+            for (u64 v = r0; v < r1; v++) {
+                const u64 nalt = d.alt0[v + 1] - d.alt0[v];
+                const u64 ns_v = d.pair0[v + 1] - d.pair0[v];
+                if (s < ns_v) {
+                    const u64 pr = d.pair0[v] + s;
+                    for (u64 t = d.pair_a0[pr]; t < d.pair_a0[pr + 1]; t++) {
+                        const int al = d.alleles[t];
+                        u32 idx = 0;                           // allele 0 or out of range -> the span
+                        if (al >= 1 && (u64)al <= nalt) idx = h.canon[h0 + rawbase + (u64)(al - 1)] & 0x7fffffffu;
+                        bits[(u64)idx * h.sw + (s >> 6)] |= 1ull << (s & 63);
+                        any = true;
+                    }
+                }
+                rawbase += nalt;
+            }
+            if (!any) bits[(s >> 6)] |= 1ull << (s & 63);      // no allele at all: reference (:466-468)
+        }
+        // sizes
+        const u64 gs = a.gs[g], spanlen = a.spanlen[g];
+        u64 eds = 2, seds = 0, nemit = 0;
+        if (nsamp == 0) {                                      // no genotype columns: all haplotypes, one {0} (:603-615)
+            for (u64 x = 0; x < a.nraw[g]; x++)
+                if (!(h.canon[h0 + x] & 0x80000000u)) { eds += h.rawlen[h0 + x]; nemit++; }
+            seds = 3;
+        } else {
+            for (u64 x = 0; x < a.nraw[g]; x++) {
+                const u32 c = h.canon[h0 + x];
+                if (c & 0x80000000u) continue;
+                u64 cnt = 0, digits = 0;
+                for (u64 s = 0; s < nsamp; s++)
+                    if (bits[(u64)c * h.sw + (s >> 6)] >> (s & 63) & 1) { cnt++; digits += ndigits((u32)s + 1); }
+                if (!cnt) continue;
+                eds += h.rawlen[h0 + x]; nemit++;
+                seds += 2 + digits + (cnt - 1);
+            }
+        }
+        eds += nemit ? nemit - 1 : 0;
+        a.eds_len[g] = eds; a.seds_len[g] = seds;
+        a.cur_after[g] = gs + spanlen;                         // group.end_pos (:404)
+    }
+}
+
+// the reference flushed before group g: [end of group g-1, gs) (:570-578); thread per group, after k_grp_samples
+__global__ void k_grp_common(VcfDev d, GrpArrays a)
+{
+    for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < d.ngrp; g += (u64)gridDim.x * blockDim.x) {
+        const u64 cur = g ? a.cur_after[g - 1] : 0;
+        const u64 gs = a.gs[g];
+        u64 clen = 0;
+        if (gs > cur && cur < d.seq_size) {
+            u64 length = gs - cur;
+            if (cur + length > d.seq_size) length = d.seq_size - cur;
+            const u64 c0 = fa_cpos(d, d.seq_start + cur + cur / d.lw);
+            clen = length < d.refc_n - c0 ? length : d.refc_n - c0;
+        }
+        a.commonlen[g] = clen;
+        if (clen) { a.eds_len[g] += clen + 2; a.seds_len[g] += 3; }
+    }
+}
+
+struct EmitArrays { const u64* eds_off; const u64* seds_off; uint8_t* eds; uint8_t* seds; };
+
+// one wave per group: common region copy (lanes = bytes), then the group symbol
+__global__ void __launch_bounds__(256) k_grp_emit(VcfDev d, GrpArrays a, HapArrays h, EmitArrays e)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 g = wave; g < d.ngrp; g += nw) {
+        uint8_t* eo = e.eds + e.eds_off[g];
+        uint8_t* so = e.seds + e.seds_off[g];
+        const u64 clen = a.commonlen[g];
+        if (clen) {
+            const u64 cur = g ? a.cur_after[g - 1] : 0;
+            const u64 c0 = fa_cpos(d, d.seq_start + cur + cur / d.lw);
+            if (lane == 0) { eo[0] = '{'; eo[clen + 1] = '}'; so[0] = '{'; so[1] = '0'; so[2] = '}'; }
+            for (u64 i = lane; i < clen; i += 64) eo[1 + i] = d.refc[c0 + i];
+            eo += clen + 2; so += 3;
+        }
+        if (lane != 0) continue;                               // the symbol itself is short: one lane
+        const u64 r0 = d.grp_r0[g];
+        const u64 h0 = h.raw0[g];
+        const u64 nsamp = d.pair0[r0 + 1] - d.pair0[r0];
+        const u64* bits = h.carried + h.bit0[g];
+        *eo++ = '{';
+        bool first = true;
+        for (u64 x = 0; x < a.nraw[g]; x++) {
+            const u32 c = h.canon[h0 + x];
+            if (c & 0x80000000u) continue;
+            u64 cnt = 0;
+            if (nsamp) {
+                for (u64 s = 0; s < nsamp; s++) cnt += bits[(u64)c * h.sw + (s >> 6)] >> (s & 63) & 1;
+                if (!cnt) continue;
+            }
+            if (!first) *eo++ = ',';
+            first = false;
+            const uint8_t* src = h.hapchars + h.rawoff[h0 + x];
+            for (u64 i = 0; i < h.rawlen[h0 + x]; i++) *eo++ = src[i];
+            if (nsamp) {
+                *so++ = '{';
+                for (u64 s = 0; s < nsamp; s++) {
+                    if (!(bits[(u64)c * h.sw + (s >> 6)] >> (s & 63) & 1)) continue;
+                    u32 id = (u32)s + 1, nd = ndigits(id);
+                    u32 xx = id;
+                    for (int dd = (int)nd - 1; dd >= 0; dd--) { so[dd] = (uint8_t)('0' + xx % 10); xx /= 10; }
+                    so += nd;
+                    *so++ = ',';
+                }
+                so[-1] = '}';
+            }
+        }
+        *eo++ = '}';
+        if (!nsamp) { so[0] = '{'; so[1] = '0'; so[2] = '}'; }
+    }
+}
+
+__global__ void k_cpos(VcfDev d, u64 file_off, u64* out) { *out = fa_cpos(d, file_off); }
+
+// tail flush (:658-665)
+__global__ void k_tail(VcfDev d, u64 cur, u64 clen, uint8_t* eo, uint8_t* so)
+{
+    const u64 c0 = fa_cpos(d, d.seq_start + cur + cur / d.lw);
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t == 0) { eo[0] = '{'; eo[clen + 1] = '}'; so[0] = '{'; so[1] = '0'; so[2] = '}'; }
+    for (u64 i = t; i < clen; i += (u64)gridDim.x * blockDim.x) eo[1 + i] = d.refc[c0 + i];
+}
+
+// ---- host ------------------------------------------------------------------------------------------
+namespace {
+
+bool next_line(const uint8_t* f, size_t n, size_t& pos, std::string& line, bool* hit_eof = nullptr)
+{
+    if (pos >= n) return false;
+    const uint8_t* nl = static_cast<const uint8_t*>(memchr(f + pos, '\n', n - pos));
+    size_t end = nl ? static_cast<size_t>(nl - f) : n;
+    line.assign(reinterpret_cast<const char*>(f + pos), end - pos);
+    if (hit_eof) *hit_eof = (nl == nullptr);
+    pos = nl ? end + 1 : n;
+    return true;
+}
+
+struct HostVariant {
+    u64 pos = 0; std::string ref; std::vector<std::string> alts; std::vector<std::vector<int>> gts;
+};
+
+enum class Skip { NONE, HEADER, MALFORMED, UNSUPPORTED_SV };
+
+// parse_alt_field :142-176 — returns false for an unsupported symbolic allele
+bool parse_alts(const std::string& field, const std::string& ref, std::vector<std::string>& alts, std::string& sv)
+{
+    std::stringstream ss(field);
+    std::string a;
+    while (std::getline(ss, a, ',')) {
+        if (!a.empty() && a[0] == '<' && a[a.size() - 1] == '>') {
+            std::string t = a.substr(1, a.size() - 2);
+            if (t == "DEL") alts.push_back("");
+            else if (t == "INS") alts.push_back(ref);
+            else { sv = t; return false; }
+        } else alts.push_back(a);
+    }
+    return true;
+}
+
+std::vector<int> parse_gt(const std::string& gt)             // :190-216
+{
+    std::vector<int> out;
+    const char delim = gt.find('/') != std::string::npos ? '/' : '|';
+    std::stringstream ss(gt);
+    std::string a;
+    while (std::getline(ss, a, delim)) {
+        if (a == ".") continue;
+        try { out.push_back(std::stoi(a)); } catch (...) { continue; }
+    }
+    return out;
+}
+
+bool parse_line(const std::string& line, Skip& skip, HostVariant& var, std::string& warn)   // :232-326
+{
+    skip = Skip::NONE;
+    if (line.empty() || line[0] == '#') { skip = Skip::HEADER; return false; }
+    std::vector<std::string> fields;
+    {
+        std::stringstream ss(line);
+        std::string tok;
+        while (std::getline(ss, tok, '\t')) if (!tok.empty()) fields.push_back(tok);
+        if (fields.size() < 5) {
+            fields.clear();
+            std::stringstream ws(line);
+            while (ws >> tok) fields.push_back(tok);
+        }
+    }
+    if (fields.size() < 5) { skip = Skip::MALFORMED; return false; }
+    var = HostVariant();
+    try { var.pos = std::stoull(fields[1]); } catch (...) { skip = Skip::MALFORMED; return false; }
+    var.ref = fields[3];
+    std::string sv;
+    if (!parse_alts(fields[4], var.ref, var.alts, sv)) {
+        warn = "Warning: Skipping variant at " + fields[0] + ":" + std::to_string(var.pos) +
+               " - Unsupported structural variant type: " + sv;
+        skip = Skip::UNSUPPORTED_SV;
+        return false;
+    }
+    if (fields.size() >= 10)
+        for (size_t i = 9; i < fields.size(); i++) {
+            std::string gt = fields[i];
+            size_t c = gt.find(':');
+            if (c != std::string::npos) gt = gt.substr(0, c);
+            var.gts.push_back(parse_gt(gt));
+        }
+    return true;
+}
+
+template <class T> void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st)
+{
+    b.ensure(sizeof(T) * (v.size() + 1) + 16);
+    if (!v.empty()) EDSX_HIP(hipMemcpyAsync(b.ptr, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, st));
+}
+
+} // namespace
+
+void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, std::string& eds,
+                      std::string& seds, VcfCounters& stats, hipStream_t st)
+{
+    stats = VcfCounters();
+    // ---- FASTA metadata (:51-86)
+    u64 seq_start, lw, seq_size;
+    {
+        size_t pos = 0;
+        std::string line;
+        bool eof = false;
+        if (!next_line(fasta, fasta_n, pos, line, &eof) || line.empty() || line[0] != '>')
+            throw FormatError("Invalid FASTA format: expected header line starting with '>'");
+        seq_start = eof ? fasta_n : pos;
+        if (!next_line(fasta, fasta_n, pos, line)) throw FormatError("FASTA file is empty");
+        lw = line.size();
+        seq_size = line.size();
+        while (next_line(fasta, fasta_n, pos, line)) {
+            if (line.empty()) continue;
+            if (line[0] == '>') break;
+            seq_size += line.size();
+        }
+    }
+    // ---- VCF records (:690-712) and the unstable sort (:715-718)
+    std::vector<HostVariant> vars;
+    {
+        size_t pos = 0;
+        std::string line, warn;
+        while (next_line(vcf, vcf_n, pos, line)) {
+            Skip skip;
+            HostVariant v;
+            const bool ok = parse_line(line, skip, v, warn);
+            if (skip == Skip::NONE) { stats.total_variants++; stats.processed_variants++; }
+            else if (skip == Skip::MALFORMED) { stats.total_variants++; stats.skipped_malformed++; }
+            else if (skip == Skip::UNSUPPORTED_SV) {
+                stats.total_variants++; stats.skipped_unsupported_sv++;
+                fprintf(stderr, "%s\n", warn.c_str());       // the reference warns on stderr (:301-302)
+            }
+            if (ok) vars.push_back(std::move(v));
+        }
+        std::sort(vars.begin(), vars.end(), [](const HostVariant& a, const HostVariant& b) { return a.pos < b.pos; });
+    }
+    const u64 nrec = vars.size();
+
+    // a reference with an empty first line has no addressable positions; the reference divides by
+    // line_width (UB), refuse instead
+    if (lw == 0) throw FormatError("Invalid FASTA format: empty first sequence line");
+
+    // ---- reference stream on the device
+    d_fasta_.ensure(fasta_n + 16);
+    EDSX_HIP(hipMemcpyAsync(d_fasta_.ptr, fasta, fasta_n, hipMemcpyHostToDevice, st));
+    const u64 body = fasta_n > seq_start ? fasta_n - seq_start : 0;
+    const u64 nblk = (body + 255) / 256;
+    ctl_.ensure(8 * 32);
+    u64* ctl = ctl_.as<u64>();
+    blkpre_.ensure(8 * (nblk + 2));
+    scan_tmp_.ensure(8 * ((std::max<u64>(nblk, nrec) + 2) / SCAN_TILE + 4));
+    refc_.ensure(body + 16);
+    u64 hctl[32] = {0};
+    hctl[0] = nblk; hctl[10] = ~0ull;
+    EDSX_HIP(hipMemcpyAsync(ctl, hctl, sizeof(hctl), hipMemcpyHostToDevice, st));
+    if (nblk) {
+        hipLaunchKernelGGL(k_fa_count, dim3(1024), dim3(256), 0, st, d_fasta_.as<uint8_t>(), (u64)fasta_n, seq_start,
+                           blkpre_.as<u64>(), nblk);
+        exclusive_scan_u64(blkpre_.as<u64>(), blkpre_.as<u64>(), ctl + 0, ctl + 1, scan_tmp_.as<u64>(), st);
+        hipLaunchKernelGGL(k_fa_compact, dim3(1024), dim3(256), 0, st, d_fasta_.as<uint8_t>(), (u64)fasta_n, seq_start,
+                           blkpre_.as<u64>(), nblk, refc_.as<uint8_t>());
+    }
+    EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    const u64 refc_n = nblk ? hctl[1] : 0;
+
+    VcfDev d{};
+    d.fasta = d_fasta_.as<uint8_t>(); d.fasta_n = fasta_n; d.seq_start = seq_start; d.seq_size = seq_size; d.lw = lw;
+    d.refc = refc_.as<uint8_t>(); d.refc_n = refc_n; d.blkpre = blkpre_.as<u64>();
+    d.nrec = nrec;
+
+    u64 cur = 0, ngrp = 0, E = 0, Q = 0;
+    u64 max_samples = 0;
+    GrpArrays ga{};
+    HapArrays ha{};
+    if (nrec) {
+        // ---- records -> SoA
+        std::vector<u64> hstart(nrec), hreflen(nrec), halt0(nrec + 1), hpair0(nrec + 1);
+        std::vector<u64> haltoff{0}, hpa0;
+        std::vector<uint8_t> haltchars;
+        std::vector<int> halleles;
+        for (u64 j = 0; j < nrec; j++) {
+            const HostVariant& v = vars[j];
+            hstart[j] = v.pos - 1;                             // wraps for POS 0 like the reference's size_t
+            hreflen[j] = v.ref.size();
+            halt0[j] = haltoff.size() - 1;
+            for (const auto& al : v.alts) { haltchars.insert(haltchars.end(), al.begin(), al.end()); haltoff.push_back(haltchars.size()); }
+            hpair0[j] = hpa0.size();
+            for (const auto& gt : v.gts) { hpa0.push_back(halleles.size()); halleles.insert(halleles.end(), gt.begin(), gt.end()); }
+            max_samples = std::max<u64>(max_samples, v.gts.size());
+        }
+        halt0[nrec] = haltoff.size() - 1;
+        hpair0[nrec] = hpa0.size();
+        hpa0.push_back(halleles.size());
+        upload(start_, hstart, st); upload(reflen_, hreflen, st); upload(alt0_, halt0, st); upload(altoff_, haltoff, st);
+        upload(altchars_, haltchars, st); upload(pair0_, hpair0, st); upload(pa0_, hpa0, st); upload(alleles_, halleles, st);
+        d.start = start_.as<u64>(); d.reflen = reflen_.as<u64>(); d.alt0 = alt0_.as<u64>(); d.altstr_off = altoff_.as<u64>();
+        d.altchars = altchars_.as<uint8_t>(); d.pair0 = pair0_.as<u64>(); d.pair_a0 = pa0_.as<u64>(); d.alleles = alleles_.as<int>();
+
+        // ---- groups
+        ends_.ensure(8 * (nrec + 2)); flag_.ensure(8 * (nrec + 2)); gidx_.ensure(8 * (nrec + 2)); grp_r0_.ensure(8 * (nrec + 2));
+        hctl[0] = nrec;
+        EDSX_HIP(hipMemcpyAsync(ctl, hctl, 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_rec_ends, dim3(1024), dim3(256), 0, st, d.start, d.reflen, nrec, ends_.as<u64>());
+        inclusive_max_scan_u64(ends_.as<u64>(), ends_.as<u64>(), ctl + 0, ctl + 2, scan_tmp_.as<u64>(), st);
+        hipLaunchKernelGGL(k_mark_groups, dim3(1024), dim3(256), 0, st, d.start, ends_.as<u64>(), nrec, flag_.as<u64>());
+        exclusive_scan_u64(flag_.as<u64>(), gidx_.as<u64>(), ctl + 0, ctl + 3, scan_tmp_.as<u64>(), st);
+        hipLaunchKernelGGL(k_group_firsts, dim3(1024), dim3(256), 0, st, flag_.as<u64>(), gidx_.as<u64>(), nrec,
+                           grp_r0_.as<u64>(), ctl + 3);
+        EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        ngrp = hctl[3];
+        d.ngrp = ngrp; d.grp_r0 = grp_r0_.as<u64>(); d.incl_end = ends_.as<u64>();
+
+        // ---- per group
+        for (DevBuf* b : {&g_gs_, &g_spanlen_, &g_cs_, &g_nraw_, &g_rawchars_, &g_ndist_, &g_bitwords_, &g_eds_, &g_seds_,
+                          &g_common_, &g_cur_}) b->ensure(8 * (ngrp + 2));
+        ga = GrpArrays{g_gs_.as<u64>(), g_spanlen_.as<u64>(), g_cs_.as<u64>(), g_nraw_.as<u64>(), g_rawchars_.as<u64>(),
+                     g_ndist_.as<u64>(), g_bitwords_.as<u64>(), g_eds_.as<u64>(), g_seds_.as<u64>(), g_common_.as<u64>(),
+                       g_cur_.as<u64>(), ctl + 10};
+        scan_tmp_.ensure(8 * ((ngrp + 2) / SCAN_TILE + 4));
+        raw0_.ensure(8 * (ngrp + 2)); rawc0_.ensure(8 * (ngrp + 2)); bit0_.ensure(8 * (ngrp + 2));
+        hctl[0] = ngrp;
+        EDSX_HIP(hipMemcpyAsync(ctl, hctl, 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_grp_count, dim3(1024), dim3(256), 0, st, d, ga);
+        exclusive_scan_u64(ga.nraw, raw0_.as<u64>(), ctl + 0, ctl + 4, scan_tmp_.as<u64>(), st);
+        exclusive_scan_u64(ga.rawchars, rawc0_.as<u64>(), ctl + 0, ctl + 5, scan_tmp_.as<u64>(), st);
+        EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        if (hctl[10] != ~0ull) {
+            // the reference dies in std::string::substr inside apply_variant_to_span (:375); rebuild its message
+            const u64 g = hctl[10];
+            std::vector<u64> r0v(2), sp(1), gsv(1);
+            EDSX_HIP(hipMemcpy(r0v.data(), grp_r0_.as<u64>() + g, 16, hipMemcpyDeviceToHost));
+            EDSX_HIP(hipMemcpy(sp.data(), g_spanlen_.as<u64>() + g, 8, hipMemcpyDeviceToHost));
+            EDSX_HIP(hipMemcpy(gsv.data(), g_gs_.as<u64>() + g, 8, hipMemcpyDeviceToHost));
+            u64 off = 0;
+            for (u64 v = r0v[0]; v < r0v[1]; v++) {
+                off = hstart[v] - gsv[0];
+                if (off > sp[0] && !vars[v].alts.empty()) break;
+            }
+            throw FormatError("basic_string::substr: __pos (which is " + std::to_string(off) + ") > this->size() (which is " +
+                              std::to_string(sp[0]) + ")");
+        }
+        const u64 nraw_total = hctl[4], rawchars_total = hctl[5];
+        const u32 sw = (u32)std::max<u64>(1, (max_samples + 63) / 64);
+        rawlen_.ensure(8 * (nraw_total + 2)); rawoff_.ensure(8 * (nraw_total + 2)); canon_.ensure(4 * (nraw_total + 2));
+        hapchars_.ensure(rawchars_total + 16);
+        ha = HapArrays{raw0_.as<u64>(), rawc0_.as<u64>(), rawlen_.as<u64>(), rawoff_.as<u64>(), canon_.as<u32>(),
+                       hapchars_.as<uint8_t>(), bit0_.as<u64>(), nullptr, sw};
+        hipLaunchKernelGGL(k_grp_haps, dim3(1024), dim3(256), 0, st, d, ga, ha);
+        exclusive_scan_u64(ga.bitwords, bit0_.as<u64>(), ctl + 0, ctl + 6, scan_tmp_.as<u64>(), st);
+        EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        carried_.ensure(8 * (hctl[6] + 2));
+        ha.carried = carried_.as<u64>();
+        hipLaunchKernelGGL(k_grp_samples, dim3(1024), dim3(256), 0, st, d, ga, ha);
+        hipLaunchKernelGGL(k_grp_common, dim3(1024), dim3(256), 0, st, d, ga);
+        exclusive_scan_u64(ga.eds_len, ga.eds_len, ctl + 0, ctl + 7, scan_tmp_.as<u64>(), st);
+        exclusive_scan_u64(ga.seds_len, ga.seds_len, ctl + 0, ctl + 8, scan_tmp_.as<u64>(), st);
+        EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+        u64 last_cur = 0;
+        EDSX_HIP(hipMemcpyAsync(&last_cur, g_cur_.as<u64>() + (ngrp - 1), 8, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        E = hctl[7]; Q = hctl[8]; cur = last_cur;
+    }
+    // ---- tail (:658-665)
+    u64 tail = 0;
+    if (cur < seq_size) {
+        // clamp exactly like read_fasta_region: by seq_size and by what the file still holds
+        u64 length = seq_size - cur;
+        // position of `cur` in the newline-free stream: ask the device map (one thread)
+        hipLaunchKernelGGL(k_cpos, dim3(1), dim3(1), 0, st, d, seq_start + cur + cur / lw, ctl + 11);
+        u64 c0 = 0;
+        EDSX_HIP(hipMemcpyAsync(&c0, ctl + 11, 8, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        tail = std::min<u64>(length, refc_n - c0);
+    }
+    const u64 Etot = E + (tail ? tail + 2 : 0), Qtot = Q + (tail ? 3 : 0);
+    d_eds_.ensure(Etot + 16); d_seds_.ensure(Qtot + 16);
+    if (ngrp) {
+        EmitArrays ea{g_eds_.as<u64>(), g_seds_.as<u64>(), d_eds_.as<uint8_t>(), d_seds_.as<uint8_t>()};
+        hipLaunchKernelGGL(k_grp_emit, dim3(2048), dim3(256), 0, st, d, ga, ha, ea);
+    }
+    if (tail)
+        hipLaunchKernelGGL(k_tail, dim3(1024), dim3(256), 0, st, d, cur, tail, d_eds_.as<uint8_t>() + E, d_seds_.as<uint8_t>() + Q);
+    eds.resize(Etot);
+    seds.resize(Qtot);
+    if (Etot) EDSX_HIP(hipMemcpyAsync(&eds[0], d_eds_.ptr, Etot, hipMemcpyDeviceToHost, st));
+    if (Qtot) EDSX_HIP(hipMemcpyAsync(&seds[0], d_seds_.ptr, Qtot, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    EDSX_HIP(hipGetLastError());
+    stats.variant_groups = ngrp;                             // :724-726
+}
+
+} // namespace edsx

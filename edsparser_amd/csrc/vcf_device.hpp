@@ -1,0 +1,27 @@
+// vcf_device.hpp — host driver of the VCF -> EDS overlay pipeline (see vcf_device.hip).
+#pragma once
+
+#include "msa_device.hpp"
+
+#include <string>
+
+namespace edsx {
+
+struct VcfCounters {   // vcf_transforms.hpp:24-35
+    u64 total_variants = 0, processed_variants = 0, skipped_malformed = 0, skipped_unsupported_sv = 0, variant_groups = 0;
+};
+
+class VcfPipeline {
+public:
+    // host buffers in; eds/seds text out (FULL brackets, no trailing newline, like the reference)
+    void run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, std::string& eds, std::string& seds,
+             VcfCounters& stats, hipStream_t st);
+
+private:
+    DevBuf d_fasta_, refc_, blkpre_, scan_tmp_, ctl_, start_, reflen_, alt0_, altoff_, altchars_, pair0_, pa0_, alleles_,
+           ends_, flag_, gidx_, grp_r0_, g_gs_, g_spanlen_, g_cs_, g_nraw_, g_rawchars_, g_ndist_, g_bitwords_, g_eds_,
+           g_seds_, g_common_, g_cur_, raw0_, rawc0_, bit0_, rawlen_, rawoff_, canon_, hapchars_, carried_, d_eds_, d_seds_,
+           d_one_;
+};
+
+} // namespace edsx

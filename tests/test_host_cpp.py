@@ -69,3 +69,22 @@ def test_msa2eds_cli_gpu(tmp_path):
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "small_l4.leds").read_text() == "{AGTC}{TC,CCTA,TA}{TATAAAT}{AAATA,AAATAGGGG,GGATA}"
     assert (tmp_path / "small_l4.seds").read_text() == "{0}{1}{2}{3}{0}{1}{2}{3}"
+
+
+@pytest.mark.gpu
+def test_vcf2eds_and_eds2leds_cli_gpu(tmp_path):
+    _build_host()
+    g = os.path.join(ROOT, "tests", "golden", "ref_data")
+    for f in ("vcf/small.vcf", "vcf/small.fa", "eds/test_iterative.eds"):
+        (tmp_path / os.path.basename(f)).write_bytes(open(os.path.join(g, f), "rb").read())
+    r = subprocess.run([os.path.join(BUILD, "vcf2eds"), "-i", str(tmp_path / "small.vcf"), "-r", str(tmp_path / "small.fa")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "small.eds").read_bytes() == open(os.path.join(g, "vcf/small.eds"), "rb").read()
+    assert (tmp_path / "small.seds").read_bytes() == open(os.path.join(g, "vcf/small.seds"), "rb").read()
+    assert "Variant groups created:     10" in r.stdout and "Success rate:               100.0%" in r.stdout
+    r = subprocess.run([os.path.join(BUILD, "eds2leds"), "-i", str(tmp_path / "test_iterative.eds"), "-l", "4"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "test_iterative_l4.leds").read_bytes() == open(os.path.join(g, "eds/test_iterative_l4.eds"), "rb").read()
+    assert "Output mode: compact" in r.stdout and "Threads: 1 (sequential)" in r.stdout

@@ -1,0 +1,89 @@
+"""GPU parity tests for VCF -> EDS / l-EDS (edsx_vcf_transform): the reference's data/vcf goldens,
+SURVEY KATs, 300 fixtures generated from the real reference library, larger random cases vs the oracle."""
+import json
+import os
+import random
+
+import pytest
+
+import oracle_lib as o
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import edsparser_amd
+    c = edsparser_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _run(ctx, vcf, fasta, l):
+    import edsparser_amd
+    try:
+        e, s, st = ctx.vcf_transform(vcf, fasta, l)
+        return {"eds": e.decode(), "seds": s.decode(), "stats": st}
+    except edsparser_amd.EdsxError as ex:
+        return {"error": ex.message}
+
+
+def _rd(rel):
+    return open(os.path.join(GOLDEN, rel), "rb").read()
+
+
+def test_kat_and_reference_goldens(ctx):
+    k = json.load(open(os.path.join(GOLDEN, "kat_vcf.json")))
+    for c in k["cases"]:
+        v = c["vcf"].encode() if "vcf" in c else _rd(c["vcf_file"])
+        f = _rd(c["fasta_file"]) if "fasta_file" in c else k["fasta_default"].encode()
+        ee = c["eds"].encode() if "eds" in c else _rd(c["eds_file"])
+        ss = c["seds"].encode() if "seds" in c else _rd(c["seds_file"])
+        got = _run(ctx, v, f, c["l"])
+        assert got.get("eds", "").encode() == ee, c["name"]
+        assert got.get("seds", "").encode() == ss, c["name"]
+
+
+def test_generated_reference_fixtures(ctx):
+    cases = json.load(open(os.path.join(GOLDEN, "gen_vcf.json")))["cases"]
+    for c in cases:
+        got = _run(ctx, c["vcf"].encode(), c["fasta"].encode(), c["l"])
+        assert got == c["expect"], c
+
+
+def _random_vcf(rng, L, nvar, ns, lw):
+    ref = "".join(rng.choice("ACGT") for _ in range(L))
+    fasta = ">chr1 synthetic\n" + "\n".join(ref[i:i + lw] for i in range(0, L, lw)) + "\n"
+    pos = sorted(rng.sample(range(1, L + 1), nvar))
+    lines = ["##fileformat=VCFv4.2", "\t".join(["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"] +
+                                                ["S%d" % i for i in range(ns)])]
+    for p in pos:
+        x = rng.random()
+        if x < 0.7:
+            r = ref[p - 1]
+            alts = [rng.choice([b for b in "ACGT" if b != r])]
+            if rng.random() < 0.1:
+                alts.append(rng.choice("ACGT"))
+        elif x < 0.85:
+            r = ref[p - 1]
+            alts = [r + "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 10)))]
+        else:
+            r = ref[p - 1:p + rng.randint(1, 10)]
+            alts = [r[0]]
+        gts = ["|".join(str(rng.randint(0, len(alts)) if rng.random() < 0.3 else 0) for _ in range(2)) for _ in range(ns)]
+        lines.append("\t".join(["chr1", str(p), ".", r, ",".join(alts), ".", "PASS", ".", "GT"] + gts))
+    return ("\n".join(lines) + "\n").encode(), fasta.encode()
+
+
+@pytest.mark.parametrize("L,nvar,ns,lw,l", [(5000, 300, 8, 60, 0), (20000, 1500, 3, 70, 0), (3000, 200, 70, 3000, 0),
+                                            (4000, 150, 4, 60, 6)])
+def test_random_larger_inputs_vs_oracle(ctx, L, nvar, ns, lw, l):
+    rng = random.Random(L + nvar)
+    vcf, fasta = _random_vcf(rng, L, nvar, ns, lw)
+    try:
+        e, s, st = o.vcf(vcf, fasta, l)
+        want = {"eds": e.decode(), "seds": s.decode(), "stats": st}
+    except o.OracleError as ex:
+        want = {"error": str(ex)}
+    assert _run(ctx, vcf, fasta, l) == want
