@@ -36,6 +36,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-baseline-mb", type=float, default=3000.0,
                     help="size of the CPU-baseline sample in MB (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     return ap.parse_args()
@@ -76,9 +78,14 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (a.gpus, world),
                   file=sys.stderr)
         sys.exit(2)
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend)
 
     ctx = edsparser_amd.Context(local_rank)
     S, L, l = a.rows, a.cols, a.context_len
@@ -91,8 +98,9 @@ def main():
 
     stitcher = None
     if world > 1:
-        from edsparser_amd.multigpu import SlabStitcher
-        stitcher = SlabStitcher(ctx, rank, world, S)
+        # boundary-segment stitch: KB-sized all_gather_object exchanges over RCCL (nccl backend)
+        from edsparser_amd.multigpu import gpu_stitcher
+        stitcher = gpu_stitcher(ctx, edsparser_amd.Context(local_rank), rank, world, S, L, dist)
 
     out = {"eds": None, "seds": None, "E": 0, "Q": 0}
 
@@ -105,7 +113,8 @@ def main():
         ctx.msa_emit_device(out["eds"].data_ptr(), out["seds"].data_ptr(), stream)
         out["E"], out["Q"] = E, Q
         if stitcher is not None:
-            stitcher.stitch(msa, n, L, out)
+            stitcher.set_sizes(E, Q)
+            out["stitch"] = stitcher.stitch()
 
     for _ in range(a.warmup):
         step()
@@ -124,7 +133,7 @@ def main():
     timing = ctx.get_timing()
     ctx.set_timing(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

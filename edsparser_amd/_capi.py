@@ -32,6 +32,12 @@ class MsaInfo(ctypes.Structure):
                  "n_slow_segments")]
 
 
+class MsaEdges(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in
+                ("n_segments", "first_is_variant", "first_cols", "first_eds_bytes", "first_seds_bytes",
+                 "last_is_variant", "last_cols", "last_eds_bytes", "last_seds_bytes")]
+
+
 def lib_path():
     return os.environ.get("EDSX_LIB") or os.path.join(_HERE, "libedsx.so")
 
@@ -66,6 +72,8 @@ def load_library():
                                          ctypes.c_void_p, P(ctypes.c_uint64), P(ctypes.c_uint64)]
     lib.edsx_msa_emit_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.edsx_msa_last_info.argtypes = [ctypes.c_void_p, P(MsaInfo)]
+    lib.edsx_msa_edge_info.argtypes = [ctypes.c_void_p, P(MsaEdges)]
+    lib.edsx_msa_copy_columns.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
     lib.edsx_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.edsx_get_timing.argtypes = [ctypes.c_void_p, P(ctypes.c_char_p), P(ctypes.c_float), P(ctypes.c_int),
                                     ctypes.c_int]
@@ -153,6 +161,16 @@ class Context:
         if rc != 0:
             raise EdsxError(rc, "no planned alignment")
         return {n: int(getattr(info, n)) for n, _ in MsaInfo._fields_}
+
+    def msa_edge_info(self):
+        e = MsaEdges()
+        self._check(self._lib.edsx_msa_edge_info(self._h, ctypes.byref(e)))
+        return {n: int(getattr(e, n)) for n, _ in MsaEdges._fields_}
+
+    def msa_copy_columns(self, col0, ncols, n_rows):
+        buf = ctypes.create_string_buffer(n_rows * ncols)
+        self._check(self._lib.edsx_msa_copy_columns(self._h, col0, ncols, buf))
+        return buf.raw
 
     def set_timing(self, on):
         self._lib.edsx_set_timing(self._h, 1 if on else 0)

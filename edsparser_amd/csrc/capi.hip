@@ -114,6 +114,25 @@ int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info)
     return EDSX_OK;
 }
 
+int edsx_msa_edge_info(edsx_ctx* ctx, edsx_msa_edges* out)
+{
+    return guarded(ctx, [&] {
+        if (!out) throw ParamError("null argument");
+        MsaPipeline::Edges e = ctx->msa.edge_info(nullptr);
+        out->n_segments = e.nseg;
+        out->first_is_variant = e.fvar; out->first_cols = e.fcols; out->first_eds_bytes = e.feds; out->first_seds_bytes = e.fseds;
+        out->last_is_variant = e.lvar; out->last_cols = e.lcols; out->last_eds_bytes = e.leds; out->last_seds_bytes = e.lseds;
+    });
+}
+
+int edsx_msa_copy_columns(edsx_ctx* ctx, uint64_t col0, uint64_t ncols, uint8_t* host_out)
+{
+    return guarded(ctx, [&] {
+        if (!host_out) throw ParamError("null argument");
+        ctx->msa.copy_columns(col0, ncols, host_out, nullptr);
+    });
+}
+
 void edsx_set_timing(edsx_ctx* ctx, int enabled) { if (ctx) ctx->msa.set_timing(enabled != 0); }
 int edsx_get_timing(edsx_ctx* ctx, const char** names, float* total_ms, int* launches, int cap)
 {

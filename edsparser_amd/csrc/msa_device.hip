@@ -1724,6 +1724,54 @@ unsigned MsaPipeline::seg_grid() const
     return (unsigned)(256 * per_cu);
 }
 
+__global__ void k_copy_columns(MsaView mv, u64 col0, u64 ncols, uint8_t* __restrict__ out)
+{
+    const u64 total = (u64)mv.S * ncols;
+    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 r = t / ncols, c = col0 + t % ncols;
+        out[t] = mv.file[mv.row_start[r] + mv.raw(c)];
+    }
+}
+
+// first / last segment of the planned alignment: type, width and text sizes (for the slab stitch)
+MsaPipeline::Edges MsaPipeline::edge_info(hipStream_t st)
+{
+    if (!planned_) throw ParamError("edge_info needs a planned alignment");
+    const u64 nseg = h_.nseg;
+    Edges e{};
+    e.nseg = nseg;
+    u64 ss[2], sl[1], eo[2], so[2], el[1], slo[1], v0 = 0, vl = 0;
+    EDSX_HIP(hipMemcpyAsync(ss, seg_start_p_, 16, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(sl, seg_start_p_ + (nseg - 1), 8, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(eo, eds_len_.as<u64>(), nseg > 1 ? 16 : 8, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(so, seds_len_.as<u64>(), nseg > 1 ? 16 : 8, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(el, eds_len_.as<u64>() + (nseg - 1), 8, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(slo, seds_len_.as<u64>() + (nseg - 1), 8, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(&v0, mv_.V, 8, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(&vl, mv_.V + ((h_.L - 1) >> 6), 8, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    e.fvar = v0 & 1;
+    e.fcols = (nseg > 1 ? ss[1] : h_.L) - ss[0];
+    e.feds = nseg > 1 ? eo[1] : h_.E;
+    e.fseds = nseg > 1 ? so[1] : h_.Q;
+    e.lvar = (vl >> ((h_.L - 1) & 63)) & 1;
+    e.lcols = h_.L - sl[0];
+    e.leds = h_.E - el[0];
+    e.lseds = h_.Q - slo[0];
+    return e;
+}
+
+void MsaPipeline::copy_columns(u64 col0, u64 ncols, uint8_t* host_out, hipStream_t st)
+{
+    if (!planned_) throw ParamError("copy_columns needs a planned alignment");
+    if (col0 + ncols > h_.L || ncols == 0) throw ParamError("copy_columns: column range outside the alignment");
+    const size_t bytes = (size_t)h_.S * ncols;
+    colbuf_.ensure(bytes + 16);
+    hipLaunchKernelGGL(k_copy_columns, dim3(256), dim3(256), 0, st, mv_, col0, ncols, colbuf_.as<uint8_t>());
+    EDSX_HIP(hipMemcpyAsync(host_out, colbuf_.ptr, bytes, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+}
+
 void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
 {
     if (!planned_) throw ParamError("edsx_msa_emit_device called without a successful plan");

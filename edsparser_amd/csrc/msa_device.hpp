@@ -90,6 +90,9 @@ public:
     void plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t st, uint64_t* eds_bytes, uint64_t* seds_bytes);
     void emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st);
     const MsaHdr& header() const { return h_; }
+    struct Edges { u64 nseg, fvar, fcols, feds, fseds, lvar, lcols, leds, lseds; };
+    Edges edge_info(hipStream_t st);
+    void copy_columns(u64 col0, u64 ncols, uint8_t* host_out, hipStream_t st);
     bool planned() const { return planned_; }
     size_t msa_bytes() const { return n_; }
 
@@ -115,7 +118,7 @@ private:
     std::vector<TimedKernel> timed_;
 
     DevBuf hdr_, rows_, vraw_, v_, wslot_, vc_, hrun_, hseg_, cnt_, wbase_, segbase_, scan_tmp_,
-           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, grec_;
+           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, grec_, colbuf_;
     u64 vc_cap_cols_ = 0;
 
     // emit-time view

@@ -96,6 +96,19 @@ typedef struct {
 } edsx_msa_info;
 int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info);
 
+/* ---- multi-GPU column slabs: what the boundary stitch needs from a planned+emitted slab ----
+ * A run that crosses a slab boundary is stitched by the caller (edsparser_amd/multigpu.py): common
+ * runs are joined textually, variant runs are recomputed from the raw columns of both sides. */
+typedef struct {
+    uint64_t n_segments;
+    uint64_t first_is_variant, first_cols, first_eds_bytes, first_seds_bytes;
+    uint64_t last_is_variant, last_cols, last_eds_bytes, last_seds_bytes;
+} edsx_msa_edges;
+int edsx_msa_edge_info(edsx_ctx* ctx, edsx_msa_edges* out);
+/* Alignment columns [col0, col0+ncols) of every row of the planned alignment, row-major
+ * (n_rows * ncols bytes) into a host buffer. */
+int edsx_msa_copy_columns(edsx_ctx* ctx, uint64_t col0, uint64_t ncols, uint8_t* host_out);
+
 /* Per-kernel device time, measured with HIP events on the stream each kernel is launched on and
  * accumulated over all plan/emit calls since edsx_set_timing(ctx, 1).  Arrays of capacity cap;
  * total_ms[i] / launches[i] is the average duration of kernel names[i].  Returns the entry count. */
