@@ -158,10 +158,17 @@ def main():
             else:
                 alg = float(n)
                 what = "input bytes"
+            traffic = a.traffic_bytes
+            if traffic is None:      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this workload
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+                    traffic = tj.get("%dx%d" % (S, L), {}).get(name)
+                except OSError:
+                    traffic = None
             ach = alg / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": a.traffic_bytes, "avg_kernel_ms": round(avg_ms, 4),
+                    "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": alg, "algorithmic_bytes": what}
         cpu = None
         if world == 1 and a.cpu_baseline_mb > 0:
