@@ -190,6 +190,12 @@ template <int I> __device__ __forceinline__ u32 byte_at(const uint4& v)
     return (w >> ((I & 3) * 8)) & 0xffu;
 }
 
+#ifndef EDSX_TILEMAP
+#define EDSX_TILEMAP 0
+#endif
+#ifndef EDSX_TILEGROUP
+#define EDSX_TILEGROUP 8
+#endif
 #ifdef EDSX_K1_NT
 #define EDSX_K1_LOAD load16u_nt
 #else
@@ -215,9 +221,19 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     u64 tile;
     {
         const u64 nt = p.ntiles, b = blockIdx.x;
+#if EDSX_TILEMAP == 1
+        // groups of G consecutive tiles per XCD, the 8 XCDs side by side: neighbouring tiles still share
+        // an L2, and all XCDs touch the same pages / DRAM rows at about the same time
+        constexpr u64 G = EDSX_TILEGROUP;
+        const u64 x = b % 8, k = b / 8;
+        const u64 full = nt / (8 * G) * (8 * G);
+        if (b < full) tile = (k / G) * (8 * G) + x * G + (k % G);
+        else tile = b;
+#else
         const u64 per = nt / 8, rem = nt % 8;     // XCD x owns per (+1 if x < rem) tiles
         const u64 x = b % 8, k = b / 8;
         tile = x * per + (x < rem ? x : rem) + k;
+#endif
     }
     const u64 q0 = tile * (u64)(cpr * 16);
     const u64 q = q0 + (u64)j * 16;
@@ -1009,51 +1025,30 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
         return true;
     }
 
-    // ---- phase A: signatures of the 16 rows of this lane
+    // ---- phase A: raw signatures of the 16 rows of this lane: sig_j(row) = sum_c byte(row,c) * W_j(c)
+    // (gaps are 0 and contribute nothing; v_mad_u32_u24 is full rate).  Rows with equal normalised
+    // columns get equal signatures; different rows collide with probability ~2^-96.
     u32 h1[16], h2[16], h3[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { h1[i] = 0x811c9dc5u; h2[i] = 0x9e3779b9u; h3[i] = 0x7f4a7c15u; }
-    uint4 lenv = make_uint4(0, 0, 0, 0);               // byte i = letters of row i so far
+    for (int i = 0; i < 16; i++) { h1[i] = 0; h2[i] = 0; h3[i] = 0; }
     const u64 slot0 = meta & META_SLOT;
     const bool scatter = (meta & META_SCATTER) != 0;
     const uint8_t* cbase = mv.vc + slot0 * (u64)mv.Spad + (u64)lane * mv.Gp;
-#define EDSX_H(I)                                                                                 \
-        {                                                                                         \
-            const u32 bch = byte_at<I>(cn);                                                       \
-            h1[I] = bch ? __umul24(h1[I], 0x9e3779u) + bch : h1[I];                               \
-            h2[I] = bch ? __umul24(h2[I], 0x85ebcbu) + (bch << 3) + 1u : h2[I];                   \
-            h3[I] = bch ? __umul24(h3[I] ^ (h3[I] >> 11), 0xc2b2afu) + bch : h3[I];               \
-        }
-#define EDSX_HASHCOL(colv)                                                                        \
-        {                                                                                         \
-            const uint4 cn = normalise_col<CHECK_NL>(colv, vmask, saw_nl);                        \
-            const uint4 nz = make_uint4(bytes_ne_mask(cn.x, 0u), bytes_ne_mask(cn.y, 0u), bytes_ne_mask(cn.z, 0u), \
-                                        bytes_ne_mask(cn.w, 0u));                                 \
-            lenv.x += nz.x & 0x01010101u; lenv.y += nz.y & 0x01010101u;                           \
-            lenv.z += nz.z & 0x01010101u; lenv.w += nz.w & 0x01010101u;                           \
-            EDSX_H(0) EDSX_H(1) EDSX_H(2) EDSX_H(3) EDSX_H(4) EDSX_H(5) EDSX_H(6) EDSX_H(7)       \
-            EDSX_H(8) EDSX_H(9) EDSX_H(10) EDSX_H(11) EDSX_H(12) EDSX_H(13) EDSX_H(14) EDSX_H(15) \
-        }
     auto col_ptr = [&](u32 c) -> const uint8_t* {
         return scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + (u64)lane * mv.Gp : cbase + (u64)c * mv.Spad;
     };
-#ifndef EDSX_PHASEA
-#define EDSX_PHASEA 1
-#endif
-#if EDSX_PHASEA == 0
-    // rolled, three columns in flight (register rotation)
-    uint4 nxt1 = ncol > 1 ? load16u(col_ptr(1)) : make_uint4(0, 0, 0, 0);
-    uint4 nxt2 = ncol > 2 ? load16u(col_ptr(2)) : make_uint4(0, 0, 0, 0);
-    uint4 cur_col = col0;
-    for (u32 c = 0; c < ncol; c++) {
-        const uint4 nxt3 = c + 3 < ncol ? load16u(col_ptr(c + 3)) : make_uint4(0, 0, 0, 0);
-        EDSX_HASHCOL(cur_col)
-        cur_col = nxt1; nxt1 = nxt2; nxt2 = nxt3;
-    }
-#elif EDSX_PHASEA == 1
-    // batches of 4 columns: 4 loads in flight, then 4 hash bodies
+    auto weight = [](u32 c, u32 j) -> u32 {
+        u32 x = (c + 1u) * 0x9e3779b1u + (j + 1u) * 0x85ebca77u;
+        x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+        return (x | 1u) & 0xffffffu;
+    };
+#define EDSX_H(I)                                                                                 \
+        {                                                                                         \
+            const u32 bch = byte_at<I>(cn);                                                       \
+            h1[I] += __umul24(bch, w1); h2[I] += __umul24(bch, w2); h3[I] += __umul24(bch, w3);   \
+        }
     for (u32 c0 = 0; c0 < ncol; c0 += 4) {
-        uint4 cvs[4];
+        uint4 cvs[4];                                  // four column loads in flight
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             cvs[j] = make_uint4(0, 0, 0, 0);
@@ -1061,19 +1056,18 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (c0 + j < ncol) EDSX_HASHCOL(cvs[j])
+            if (c0 + j < ncol) {
+                const uint4 cn = normalise_col<CHECK_NL>(cvs[j], vmask, saw_nl);
+                const u32 w1 = weight(c0 + j, 0), w2 = weight(c0 + j, 1), w3 = weight(c0 + j, 2);
+                EDSX_H(0) EDSX_H(1) EDSX_H(2) EDSX_H(3) EDSX_H(4) EDSX_H(5) EDSX_H(6) EDSX_H(7)
+                EDSX_H(8) EDSX_H(9) EDSX_H(10) EDSX_H(11) EDSX_H(12) EDSX_H(13) EDSX_H(14) EDSX_H(15)
+            }
         }
     }
-#else
-    // rolled, load and use (latency hidden by the other waves only)
-    for (u32 c = 0; c < ncol; c++) {
-        const uint4 cv = c == 0 ? col0 : load16u(col_ptr(c));
-        EDSX_HASHCOL(cv)
-    }
-#endif
-#undef EDSX_HASHCOL
 #undef EDSX_H
-    // ---- phase B: groups in order of first appearance
+    // ---- phase B: raw groups in order of first appearance; each is keyed by a 96-bit hash of its
+    // representative's gap-stripped string (+ length), so that raw groups spelling the same string
+    // (same letters, other gap placement) fall together in fast_assign
     while (ballot64(any4(rm))) {
         int leader;
         const u32 i0 = first_remaining(rm, leader);
@@ -1084,7 +1078,6 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
         }
         const u32 r1 = (u32)__builtin_amdgcn_readlane((int)m1, leader), r2 = (u32)__builtin_amdgcn_readlane((int)m2, leader);
         const u32 r3 = (u32)__builtin_amdgcn_readlane((int)m3, leader);
-        const u32 len = leader_byte(lenv, leader, i0);
         uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -1093,11 +1086,31 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
             if (h1[i + 8] == r1 && h2[i + 8] == r2 && h3[i + 8] == r3) e2 |= 0xffu << (i * 8);
             if (h1[i + 12] == r1 && h2[i + 12] == r2 && h3[i + 12] == r3) e3 |= 0xffu << (i * 8);
         }
-        // rows of equal signature but other length cannot exist in practice; the length is part of the key
-        const uint4 lm = bytes_eq_mask(lenv, len * 0x01010101u);
-        const uint4 eq = make_uint4(e0 & rm.x & lm.x, e1 & rm.y & lm.y, e2 & rm.z & lm.z, e3 & rm.w & lm.w);
-        if (!fast_assign(G, rm, eq, ((u64)r2 << 32) | r1, ((u64)len << 32) | r3, len, lane, i0 * 64u + (u32)leader))
-            return false;
+        const uint4 eq = make_uint4(e0 & rm.x, e1 & rm.y, e2 & rm.z, e3 & rm.w);
+        // the representative's string: lane = column
+        const u32 rep_row = i0 * 64u + (u32)leader;
+        u32 ch = 0;
+        if (lane < ncol) {
+            const u64 sl = scatter ? mv.slot(seg_a + lane) : slot0 + lane;
+            ch = mv.vc[sl * (u64)mv.Spad + vc_pos(rep_row, mv.Gp)];
+            if (ch == '-' || ch == '\n') ch = 0;
+        }
+        const u64 nzm = ballot64(ch != 0);
+        const u32 len = (u32)__builtin_popcountll(nzm);
+        const u32 pos = mbcnt(nzm);
+        u32 t1 = 0, t2 = 0, t3 = 0;
+        if (ch) {
+            u32 x = (ch + 1u) * 0x9e3779b1u ^ (pos + 1u) * 0x85ebca77u;
+            x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15;
+            t1 = x * 0x735a2d97u; t1 ^= t1 >> 15;
+            t2 = (x ^ 0x5bd1e995u) * 0xc2b2ae3du; t2 ^= t2 >> 13;
+            t3 = (x + 0x27d4eb2fu) * 0x165667b1u; t3 ^= t3 >> 16;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            t1 ^= __shfl_xor(t1, o, 64); t2 ^= __shfl_xor(t2, o, 64); t3 ^= __shfl_xor(t3, o, 64);
+        }
+        const u64 klo = ((u64)uniform32(t2) << 32) | uniform32(t1), khi = ((u64)len << 32) | uniform32(t3);
+        if (!fast_assign(G, rm, eq, klo, khi, len, lane, rep_row)) return false;
     }
     return true;
 }
@@ -1310,10 +1323,95 @@ __device__ __forceinline__ u32 fast_emit_ids(const uint4& gid, u32 k, uint8_t* t
     return run;
 }
 
+// ---- id lists with consecutive rows per lane (k <= 8) ---------------------------------------------
+// The group ids arrive row-strided (lane holds rows lane, lane+64, ...).  One LDS transpose gives
+// every lane 16 CONSECUTIVE rows (lane*16 .. lane*16+15); a lane's members of a group are then
+// adjacent in the output, so placement is: bytes per (lane, group) by SWAR, one wave scan of the
+// packed 16-bit counts, and a packed per-lane cursor that advances while the lane walks its rows.
+// tok_t is the token table transposed to [i*64 + lane] (row lane*16+i), tlv_c the token lengths of
+// this lane's 16 rows as SWAR bytes (0 where the row does not exist).
+template <int NP>   // NP = 1: k <= 4, NP = 2: k <= 8
+__device__ __forceinline__ u32 fast_emit_ids_rows(const uint4& gid_strided, u32 k, uint8_t* text, uint8_t* xpose,
+                                                  const u64* tok_t, const uint4& tlv_c, u32 lane)
+{
+    // transpose: strided row r sits at byte (r%64)*16 + r/64 of the 1 KB record image
+    *reinterpret_cast<uint4*>(xpose + lane * 16u) = gid_strided;
+    uint32_t gw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const u32 r = lane * 16u + j;
+        gw[j >> 2] |= (uint32_t)xpose[(r & 63u) * 16u + (r >> 6)] << ((j & 3) * 8);
+    }
+    const uint4 gid = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+    // bytes of every (lane, group), 16-bit fields
+    u64 cnt[2] = {0, 0};
+#pragma unroll
+    for (int g = 0; g < 4 * NP; g++) {
+        if ((u32)g < k) {
+            const uint4 m = bytes_eq_mask(gid, (uint32_t)g * 0x01010101u);
+            u32 c = __builtin_amdgcn_sad_u8(tlv_c.x & m.x, 0u, 0u);
+            c = __builtin_amdgcn_sad_u8(tlv_c.y & m.y, 0u, c);
+            c = __builtin_amdgcn_sad_u8(tlv_c.z & m.z, 0u, c);
+            c = __builtin_amdgcn_sad_u8(tlv_c.w & m.w, 0u, c);
+            cnt[g >> 2] |= (u64)c << (16 * (g & 3));
+        }
+    }
+    u64 inc[2] = {cnt[0], cnt[1]};
+#pragma unroll
+    for (int h = 0; h < NP; h++)
+        for (int o = 1; o < 64; o <<= 1) { u64 a = __shfl_up(inc[h], o, 64); if (lane >= (u32)o) inc[h] += a; }
+    u64 tot[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < NP; h++)
+        tot[h] = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(inc[h] >> 32), 63) << 32) |
+                 (u32)__builtin_amdgcn_readlane((int)(u32)inc[h], 63);
+    // group starts (wave-uniform) and this lane's cursors = start + 1 + bytes of the lanes before
+    u64 base[2] = {0, 0};
+    u32 run = 0, gstart[8], gend[8];
+#pragma unroll
+    for (int g = 0; g < 4 * NP; g++) {
+        gstart[g] = run;
+        if ((u32)g < k) {
+            const u32 T = (u32)(tot[g >> 2] >> (16 * (g & 3))) & 0xffffu;
+            base[g >> 2] |= (u64)(run + 1) << (16 * (g & 3));
+            run += 1 + T;
+        }
+        gend[g] = run;
+    }
+#pragma unroll
+    for (int h = 0; h < NP; h++) base[h] += inc[h] - cnt[h];   // fields stay < 2^16: no carries
+#define EDSX_R(I)                                                                                 \
+    {                                                                                             \
+        const u32 g = byte_at<I>(gid);                                                            \
+        if (g != 0xffu) {                                                                         \
+            const u64 t = tok_t[(u32)I * 64u + lane];                                             \
+            const u32 tl = (u32)(t >> 56);                                                        \
+            const u32 shf = 16u * (g & 3u);                                                       \
+            const u64 bsel = (NP == 2 && (g & 4u)) ? base[NP - 1] : base[0];                      \
+            uint8_t* dst = text + ((u32)(bsel >> shf) & 0xffffu);                                 \
+            dst[0] = (uint8_t)t; dst[1] = (uint8_t)(t >> 8);                                      \
+            if (tl >= 3) dst[2] = (uint8_t)(t >> 16);                                             \
+            if (tl >= 4) dst[3] = (uint8_t)(t >> 24);                                             \
+            if (tl >= 5) dst[4] = (uint8_t)(t >> 32);                                             \
+            if (NP == 2 && (g & 4u)) base[NP - 1] += (u64)tl << shf; else base[0] += (u64)tl << shf; \
+        }                                                                                         \
+    }
+    EDSX_R(0) EDSX_R(1) EDSX_R(2) EDSX_R(3) EDSX_R(4) EDSX_R(5) EDSX_R(6) EDSX_R(7)
+    EDSX_R(8) EDSX_R(9) EDSX_R(10) EDSX_R(11) EDSX_R(12) EDSX_R(13) EDSX_R(14) EDSX_R(15)
+#undef EDSX_R
+    if (lane == 0) {                               // braces last: the closing one replaces the final ','
+#pragma unroll
+        for (int g = 0; g < 4 * NP; g++) if ((u32)g < k) { text[gstart[g]] = '{'; text[gend[g] - 1] = '}'; }
+    }
+    return run;
+}
+
 __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
 {
     __shared__ __attribute__((aligned(16))) u64 tok_sh[1024];
+    __shared__ __attribute__((aligned(16))) u64 tok_t[1024];
     __shared__ __attribute__((aligned(16))) uint8_t stage_sh[4][FAST_STAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t xpose_sh[4][1024];
     const MsaView& mv = p.mv;
     if (mv.hdr->status) return;
     const u32 lane = threadIdx.x & 63, wv = uniform32(threadIdx.x >> 6);
@@ -1324,9 +1422,21 @@ __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
         for (int i = (int)nd - 1; i >= 0; i--) { t |= (u64)('0' + v % 10u) << (8 * i); v /= 10u; }
         t |= (u64)',' << (8 * nd);
         tok_sh[r] = t | ((u64)(nd + 1) << 56);
+        tok_t[(r & 15u) * 64u + (r >> 4)] = t | ((u64)(nd + 1) << 56);   // row = lane*16 + i  ->  [i*64 + lane]
     }
     __syncthreads();
     uint8_t* stage = stage_sh[wv];
+    uint8_t* xpose = xpose_sh[wv];
+    uint4 tlv_c;                                   // token lengths of rows lane*16 .. lane*16+15 (0: no such row)
+    {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const u32 r = lane * 16u + j;
+            if (r < mv.S) w[j >> 2] |= (ndigits(r + 1) + 1) << ((j & 3) * 8);
+        }
+        tlv_c = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 
     const u64 nseg = *p.nseg_ptr;
     const u64 p0 = mv.vbit(0) ? 0 : 1;
@@ -1370,13 +1480,9 @@ __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
             const u32 sh = (u32)goff & 15u;
             uint8_t* text = stage + sh;                    // LDS offset == global offset (mod 16)
             u32 n;
-            switch (G.k) {
-                case 1: n = fast_emit_ids<1>(G.gid, 1, text, tok_sh, lane); break;
-                case 2: n = fast_emit_ids<2>(G.gid, 2, text, tok_sh, lane); break;
-                case 3: n = fast_emit_ids<3>(G.gid, 3, text, tok_sh, lane); break;
-                case 4: n = fast_emit_ids<4>(G.gid, 4, text, tok_sh, lane); break;
-                default: n = fast_emit_ids<0>(G.gid, G.k, text, tok_sh, lane); break;
-            }
+            if (G.k <= 4) n = fast_emit_ids_rows<1>(G.gid, G.k, text, xpose, tok_t, tlv_c, lane);
+            else if (G.k <= 8) n = fast_emit_ids_rows<2>(G.gid, G.k, text, xpose, tok_t, tlv_c, lane);
+            else n = fast_emit_ids<0>(G.gid, G.k, text, tok_sh, lane);
 #ifdef EDSX_DIAG
             { DIAG_STAMP(tt); t_i = tt; }
 #endif
@@ -1400,13 +1506,16 @@ __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
                 if (lane == 0) e[0] = '{';
                 u32 eo = 1;
                 const u32 ncol = (u32)(meta >> 48) & 0xffu;
-                for (u32 g = 0; g < G.k; g++) {
-                    u32 len;
-                    if (ncol == 1) {
-                        const u32 c = (u32)__builtin_amdgcn_readlane((int)(u32)G.key_lo, (int)g);
-                        len = c ? 1u : 0u;
-                        if (lane == 0 && c) e[eo] = (uint8_t)c;
-                    } else {                              // lane = column: the representative row's letters
+                if (ncol == 1) {                          // lane g holds group g's letter (0 = empty string)
+                    const u32 c = lane < G.k ? (u32)G.key_lo : 0u;
+                    const u64 nz = ballot64(c != 0);
+                    const u32 at = 1 + lane + mbcnt(nz);  // '{' + one separator per earlier group + earlier letters
+                    if (lane < G.k) {
+                        if (c) e[at] = (uint8_t)c;
+                        e[at + (c ? 1 : 0)] = (lane + 1 < G.k) ? ',' : '}';
+                    }
+                } else {
+                    for (u32 g = 0; g < G.k; g++) {       // lane = column: the representative row's letters
                         const u32 r = (u32)__builtin_amdgcn_readlane((int)G.rep, (int)g);
                         u32 ch = 0;
                         if (lane < ncol) {
@@ -1415,11 +1524,11 @@ __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
                             if (ch == '-' || ch == '\n') ch = 0;
                         }
                         const u64 m = ballot64(ch != 0);
-                        len = (u32)__builtin_popcountll(m);
+                        const u32 len = (u32)__builtin_popcountll(m);
                         if (ch) e[eo + mbcnt(m)] = (uint8_t)ch;
+                        if (lane == 0) e[eo + len] = (g + 1 < G.k) ? ',' : '}';
+                        eo += len + 1;
                     }
-                    if (lane == 0) e[eo + len] = (g + 1 < G.k) ? ',' : '}';
-                    eo += len + 1;
                 }
             }
         }
@@ -1600,15 +1709,15 @@ void MsaPipeline::plan_body(hipStream_t st)
     //   cfg 1: T=512  RPT=16  (2 workgroups/CU)
     //   cfg 2: T=1024 RPT=8   (2 workgroups/CU, <= 64 VGPRs)
     static int cfg_env = -1;
-    if (cfg_env < 0) { const char* e = getenv("EDSX_K1"); cfg_env = e ? atoi(e) : 1; if (cfg_env < 0 || cfg_env > 2) cfg_env = 1; }
+    if (cfg_env < 0) { const char* e = getenv("EDSX_K1"); cfg_env = e ? atoi(e) : 1; if (cfg_env < 0 || cfg_env > 3) cfg_env = 1; }
     int cfg = cfg_env;
-    const int T = cfg == 1 ? 512 : 1024, RPT = cfg == 2 ? 8 : 16;
+    const int T = (cfg == 1 || cfg == 3) ? 512 : 1024, RPT = cfg == 2 ? 8 : 16;
     u32 cpr_log2 = 8;
     while (cpr_log2 > 2 && (u64)RPT * (T >> cpr_log2) < S) cpr_log2--;
     const bool hold = (u64)RPT * (T >> cpr_log2) >= S;
     const u64 W = 16ull << cpr_log2;
     const u64 ntiles = (Draw + W - 1) / W;
-    const size_t colbuf_bytes = cfg == 0 ? 96 * 1024 : 64 * 1024;
+    const size_t colbuf_bytes = cfg == 0 ? 96 * 1024 : (cfg == 3 ? 48 * 1024 : 64 * 1024);
     if (ntiles > 0x7fffffffull) throw FormatError("MSA too large for one launch");
     if (colbuf_bytes < (size_t)S * 8) throw FormatError(status_message(ST_TOO_MANY_ROWS));
 
@@ -1624,6 +1733,10 @@ void MsaPipeline::plan_body(hipStream_t st)
         if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
         else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
         else launch_k1<512, 16, false, false, 4>(kp, colbuf_bytes, st);
+    } else if (cfg == 3) {                                   // 3 workgroups / CU: <= 84 VGPRs
+        if (lane_rows) launch_k1<512, 16, true, true, 6>(kp, colbuf_bytes, st);
+        else if (hold) launch_k1<512, 16, true, false, 6>(kp, colbuf_bytes, st);
+        else launch_k1<512, 16, false, false, 6>(kp, colbuf_bytes, st);
     } else if (cfg == 2) {
         if (hold) launch_k1<1024, 8, true, false, 8>(kp, colbuf_bytes, st);
         else launch_k1<1024, 8, false, false, 8>(kp, colbuf_bytes, st);
