@@ -1123,20 +1123,6 @@ __device__ __forceinline__ uint4 fast_load_col(const MsaView& mv, u64 meta, u32 
     return load16u(mv.vc + (meta & META_SLOT) * (u64)mv.Spad + (u64)lane * mv.Gp);
 }
 
-#ifdef EDSX_DIAG
-__device__ u64 g_diag[2][8][3];      // [kernel][class][sum cycles, count, max cycles]
-__device__ u64 g_stage[8];           // emit, class 0: group, ids, flush, eds ; count class 2: phaseA, phaseB
-#define DIAG_STAMP(var) const u64 var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
-__device__ __forceinline__ void diag_add(int kern, u32 ncol, u32 k, u64 cyc, u32 lane)
-{
-    if (lane) return;
-    int cls = (ncol == 1 ? 0 : (ncol <= 8 ? 2 : 4)) + (k > 4 ? 1 : 0);
-    if (k > 16) cls = 6 + (ncol > 8 ? 1 : 0);
-    atomicAdd(&g_diag[kern][cls][0], cyc);
-    atomicAdd(&g_diag[kern][cls][1], 1ull);
-    atomicMax(&g_diag[kern][cls][2], cyc);
-}
-#endif
 
 // K3 fast: sizes of the variant segments.  Variant and common segments alternate, so the
 // variant ones are seg = 2*vi + p0.
@@ -1161,15 +1147,16 @@ __global__ void __launch_bounds__(256) k_seg_count_fast(FastParams p)
         const u64 seg = 2 * vi + p0;
         // prefetch: next segment's first column and the descriptor after it
         const uint4 col_n = fast_load_col(mv, meta_n, lane);
-        const u64 meta_nn = vi + 2 * nw < nvs ? uniform64(p.segmeta[2 * (vi + 2 * nw) + p0]) : 0;
+        const u64 meta_v = p.segmeta[2 * (vi + 2 * nw < nvs ? vi + 2 * nw : vi) + p0];   // scalar after the wait below
 
-#ifdef EDSX_DIAG
-        const u64 t_diag = __builtin_amdgcn_s_memtime();
-#endif
         bool fast = (meta & META_FAST) != 0;
         FastGroups G;
         if (fast) fast = fast_group<true>(mv, (meta & META_SCATTER) ? uniform64(p.seg_start[seg]) : 0, meta, col, lane, vmask, G, saw_nl);
         uint8_t* rec = p.grec + vi * (u64)GREC_BYTES;
+        // wait for the prefetched column here, before this segment's stores are queued behind it
+        // (vmcnt retires in issue order: see k_emit_variant_fast)
+        asm volatile("" :: "v"(col_n.x), "v"(col_n.y), "v"(col_n.z), "v"(col_n.w), "v"(meta_v));
+        const u64 meta_nn = vi + 2 * nw < nvs ? uniform64(meta_v) : 0;
         if (fast) {
             *reinterpret_cast<uint4*>(rec + lane * 16u) = G.gid;
             if (lane < G.k) {
@@ -1185,9 +1172,6 @@ __global__ void __launch_bounds__(256) k_seg_count_fast(FastParams p)
             rec[GREC_K] = 0;                              // not a fast segment
             p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;
         }
-#ifdef EDSX_DIAG
-        if (fast) diag_add(0, (u32)(meta >> 48) & 0xff, G.k, __builtin_amdgcn_s_memtime() - t_diag, lane);
-#endif
         vi += nw; meta = meta_n; meta_n = meta_nn; col = col_n;
     }
     if (saw_nl) atomicOr(&mv.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));
@@ -1247,17 +1231,35 @@ __device__ __forceinline__ u32 block_offsets_dyn(u32 gi, u32 k, u32& cur_l, u32 
     return off;
 }
 
-// Token text -> LDS.  Byte stores only: a misaligned ds_write_b32/b16 is replayed lane by lane on
-// gfx950 (measured: ~7000 cycles per wave instruction), four aligned byte stores are ~50x cheaper.
+// Token bytes -> LDS as single-byte stores.  Written in C (d[0] = ..; d[1] = ..) hipcc fuses the four
+// stores into one ds_write_b32 at an unaligned address, which the LDS executes ~10x slower
+// (SQ_LDS_IDX_ACTIVE: 28 cycles per instruction).  a = LDS byte address.
+__device__ __forceinline__ void lds_put2(u32 a, u32 t)
+{
+    const u32 t8 = t >> 8;
+    asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1" :: "v"(a), "v"(t), "v"(t8) : "memory");
+}
+__device__ __forceinline__ void lds_put4(u32 a, u32 t)
+{
+    const u32 t8 = t >> 8;          // d16_hi stores bits 23:16: bytes 2 and 3 need no further shifts
+    asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\t"
+                 "ds_write_b8_d16_hi %0, %1 offset:2\n\tds_write_b8_d16_hi %0, %2 offset:3"
+                 :: "v"(a), "v"(t), "v"(t8) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void lds_put1(u32 a, u32 v)
+{
+    asm volatile("ds_write_b8 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
+}
 template <bool MIXED>
 __device__ __forceinline__ void write_token(uint8_t* dst, u64 t)
 {
-    dst[0] = (uint8_t)t; dst[1] = (uint8_t)(t >> 8);
-    if (!MIXED) { dst[2] = (uint8_t)(t >> 16); dst[3] = (uint8_t)(t >> 24); return; }
+    const u32 a = (u32)(uintptr_t)dst;    // LDS byte address (low half of the flat address)
+    if (!MIXED) { lds_put4(a, (u32)t); return; }
     const u32 tl = (u32)(t >> 56);
-    if (tl >= 3) dst[2] = (uint8_t)(t >> 16);
-    if (tl >= 4) dst[3] = (uint8_t)(t >> 24);
-    if (tl >= 5) dst[4] = (uint8_t)(t >> 32);
+    lds_put2(a, (u32)t);
+    if (tl >= 3) lds_put1<2>(a, (u32)(t >> 16));
+    if (tl >= 4) lds_put1<3>(a, (u32)(t >> 24));
+    if (tl >= 5) lds_put1<4>(a, (u32)(t >> 32));
 }
 
 // Writes the id lists of the k groups into `text`; returns the number of bytes (= k + tokens).
@@ -1323,82 +1325,128 @@ __device__ __forceinline__ u32 fast_emit_ids(const uint4& gid, u32 k, uint8_t* t
     return run;
 }
 
-// ---- id lists with consecutive rows per lane (k <= 8) ---------------------------------------------
-// The group ids arrive row-strided (lane holds rows lane, lane+64, ...).  One LDS transpose gives
-// every lane 16 CONSECUTIVE rows (lane*16 .. lane*16+15); a lane's members of a group are then
-// adjacent in the output, so placement is: bytes per (lane, group) by SWAR, one wave scan of the
-// packed 16-bit counts, and a packed per-lane cursor that advances while the lane walks its rows.
-// tok_t is the token table transposed to [i*64 + lane] (row lane*16+i), tlv_c the token lengths of
-// this lane's 16 rows as SWAR bytes (0 where the row does not exist).
-template <int NP>   // NP = 1: k <= 4, NP = 2: k <= 8
-__device__ __forceinline__ u32 fast_emit_ids_rows(const uint4& gid_strided, u32 k, uint8_t* text, uint8_t* xpose,
-                                                  const u64* tok_t, const uint4& tlv_c, u32 lane)
+// ---- id lists, k <= 4*NP: packed prefix sums per block of 64 rows ---------------------------------
+// Lane `lane` owns rows lane, lane+64, ... (block i = rows i*64 .. i*64+63), exactly as the group ids
+// arrive.  The members of a group inside one block are adjacent in the output, so the lanes of a
+// block store to consecutive LDS addresses (no bank conflicts beyond the overlap of the k groups).
+// Per block one DPP wave scan ranks the rows of ALL groups at once: every lane adds its weight into
+// the 8-bit field of its group (4 groups per dword).  The weight is 1 in the blocks whose ids all
+// have 3 digits (rank*4 = bytes) and the token length in blocks 0 and 1, whose ids have 1-2 / 2-3
+// digits (64 tokens of <= 3 bytes and 35*3 + 29*4 bytes both stay below 256).  Block 15 (ids
+// 961..1024, up to 281 bytes) is scanned with 16-bit fields.  Rows that do not exist weigh 0, so
+// every block is processed unconditionally: straight-line code whose independent scans interleave.
+//   wv    byte i: weight of row i*64+lane (0: no such row)          -- lane constant
+//   tokc  [i]: the first four bytes of that row's token "ddd,"      -- lane constant
+__device__ __forceinline__ u32 dpp_add(u32 v, u32 moved) { return v + moved; }
+template <int CTRL, int ROWMASK> __device__ __forceinline__ u32 dpp_take(u32 v)
 {
-    // transpose: strided row r sits at byte (r%64)*16 + r/64 of the 1 KB record image
-    *reinterpret_cast<uint4*>(xpose + lane * 16u) = gid_strided;
-    uint32_t gw[4] = {0, 0, 0, 0};
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);   // lanes without a source get 0
+}
+__device__ __forceinline__ u32 wave_scan_incl(u32 v)
+{
+    v += dpp_take<0x111, 0xf>(v);        // row_shr:1
+    v += dpp_take<0x112, 0xf>(v);        // row_shr:2
+    v += dpp_take<0x114, 0xf>(v);        // row_shr:4
+    v += dpp_take<0x118, 0xf>(v);        // row_shr:8
+    v += dpp_take<0x142, 0xa>(v);        // row_bcast:15 -> rows 1, 3
+    v += dpp_take<0x143, 0xc>(v);        // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+template <int NP>   // NP = 1: k <= 4, NP = 2: k <= 8
+__device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8_t* text, const u32 (&tokc)[16],
+                                                  const uint4& wv, u32 lane)
+{
+    const u32 tbase = (u32)(uintptr_t)text;   // LDS byte address (low half of the flat address)
+    u32 ex[NP][15];                // exclusive packed prefix of the row inside its block (8-bit fields)
+    u32 tot[NP][15];               // packed block totals (wave-uniform)
+    u32 ex15[2 * NP], tot15[2 * NP];
+    // byte totals, 16-bit fields: A[2h] = groups 4h (low half) and 4h+2, A[2h+1] = groups 4h+1 and 4h+3
+    u32 A[2 * NP];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const u32 r = lane * 16u + j;
-        gw[j >> 2] |= (uint32_t)xpose[(r & 63u) * 16u + (r >> 6)] << ((j & 3) * 8);
+    for (int j = 0; j < 2 * NP; j++) { A[j] = 0; ex15[j] = 0; tot15[j] = 0; }
+#define EDSX_A(I)                                                                                 \
+    {                                                                                             \
+        const u32 gi = byte_at<I>(gid);                                                           \
+        const u32 f = byte_at<I>(wv) << ((gi << 3) & 31u);                                        \
+        _Pragma("unroll") for (int h = 0; h < NP; h++) {                                          \
+            const u32 fh = NP == 1 ? f : ((gi >> 2) == (u32)h ? f : 0u);                          \
+            const u32 inc = wave_scan_incl(fh);                                                   \
+            ex[h][I] = inc - fh;                                                                  \
+            const u32 t = (u32)__builtin_amdgcn_readlane((int)inc, 63);                           \
+            tot[h][I] = t;                                                                        \
+            const u32 lo = t & 0x00ff00ffu, hi = (t >> 8) & 0x00ff00ffu;                          \
+            A[2 * h] += (I >= 2) ? lo << 2 : lo;                                                  \
+            A[2 * h + 1] += (I >= 2) ? hi << 2 : hi;                                              \
+        }                                                                                         \
     }
-    const uint4 gid = make_uint4(gw[0], gw[1], gw[2], gw[3]);
-    // bytes of every (lane, group), 16-bit fields
-    u64 cnt[2] = {0, 0};
+    EDSX_A(0) EDSX_A(1) EDSX_A(2) EDSX_A(3) EDSX_A(4) EDSX_A(5) EDSX_A(6) EDSX_A(7)
+    EDSX_A(8) EDSX_A(9) EDSX_A(10) EDSX_A(11) EDSX_A(12) EDSX_A(13) EDSX_A(14)
+#undef EDSX_A
+    {
+        const u32 gi = byte_at<15>(gid);
+        const u32 f = byte_at<15>(wv) << (((gi >> 1) & 1u) * 16u);
 #pragma unroll
-    for (int g = 0; g < 4 * NP; g++) {
-        if ((u32)g < k) {
-            const uint4 m = bytes_eq_mask(gid, (uint32_t)g * 0x01010101u);
-            u32 c = __builtin_amdgcn_sad_u8(tlv_c.x & m.x, 0u, 0u);
-            c = __builtin_amdgcn_sad_u8(tlv_c.y & m.y, 0u, c);
-            c = __builtin_amdgcn_sad_u8(tlv_c.z & m.z, 0u, c);
-            c = __builtin_amdgcn_sad_u8(tlv_c.w & m.w, 0u, c);
-            cnt[g >> 2] |= (u64)c << (16 * (g & 3));
+        for (int j = 0; j < 2 * NP; j++) {
+            const u32 fj = ((gi >> 2) == (u32)(j >> 1) && (gi & 1u) == (u32)(j & 1)) ? f : 0u;
+            const u32 inc = wave_scan_incl(fj);
+            ex15[j] = inc - fj;
+            tot15[j] = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            A[j] += tot15[j];
         }
     }
-    u64 inc[2] = {cnt[0], cnt[1]};
+    // group starts, and the packed cursors (same field layout as A)
+    u32 C[2 * NP];
 #pragma unroll
-    for (int h = 0; h < NP; h++)
-        for (int o = 1; o < 64; o <<= 1) { u64 a = __shfl_up(inc[h], o, 64); if (lane >= (u32)o) inc[h] += a; }
-    u64 tot[2] = {0, 0};
-#pragma unroll
-    for (int h = 0; h < NP; h++)
-        tot[h] = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(inc[h] >> 32), 63) << 32) |
-                 (u32)__builtin_amdgcn_readlane((int)(u32)inc[h], 63);
-    // group starts (wave-uniform) and this lane's cursors = start + 1 + bytes of the lanes before
-    u64 base[2] = {0, 0};
-    u32 run = 0, gstart[8], gend[8];
+    for (int j = 0; j < 2 * NP; j++) C[j] = 0;
+    u32 run = 0, gstart[4 * NP], gend[4 * NP];
 #pragma unroll
     for (int g = 0; g < 4 * NP; g++) {
         gstart[g] = run;
         if ((u32)g < k) {
-            const u32 T = (u32)(tot[g >> 2] >> (16 * (g & 3))) & 0xffffu;
-            base[g >> 2] |= (u64)(run + 1) << (16 * (g & 3));
-            run += 1 + T;
+            const int j = 2 * (g >> 2) + (g & 1), sh = 16 * ((g >> 1) & 1);
+            C[j] |= (run + 1) << sh;
+            run += 1 + ((A[j] >> sh) & 0xffffu);
         }
         gend[g] = run;
     }
-#pragma unroll
-    for (int h = 0; h < NP; h++) base[h] += inc[h] - cnt[h];   // fields stay < 2^16: no carries
-#define EDSX_R(I)                                                                                 \
+#define EDSX_CUR(gi) ((NP == 1 ? ((gi & 1u) ? C[1] : C[0])                                         \
+                               : ((gi & 4u) ? ((gi & 1u) ? C[2 * NP - 1] : C[2 * NP - 2]) : ((gi & 1u) ? C[1] : C[0]))) \
+                      >> (((gi >> 1) & 1u) * 16u) & 0xffffu)
+#define EDSX_B(I)                                                                                 \
     {                                                                                             \
-        const u32 g = byte_at<I>(gid);                                                            \
-        if (g != 0xffu) {                                                                         \
-            const u64 t = tok_t[(u32)I * 64u + lane];                                             \
-            const u32 tl = (u32)(t >> 56);                                                        \
-            const u32 shf = 16u * (g & 3u);                                                       \
-            const u64 bsel = (NP == 2 && (g & 4u)) ? base[NP - 1] : base[0];                      \
-            uint8_t* dst = text + ((u32)(bsel >> shf) & 0xffffu);                                 \
-            dst[0] = (uint8_t)t; dst[1] = (uint8_t)(t >> 8);                                      \
-            if (tl >= 3) dst[2] = (uint8_t)(t >> 16);                                             \
-            if (tl >= 4) dst[3] = (uint8_t)(t >> 24);                                             \
-            if (tl >= 5) dst[4] = (uint8_t)(t >> 32);                                             \
-            if (NP == 2 && (g & 4u)) base[NP - 1] += (u64)tl << shf; else base[0] += (u64)tl << shf; \
+        const u32 gi = byte_at<I>(gid);                                                           \
+        const u32 pk = NP == 1 ? ex[0][I] : ((gi & 4u) ? ex[NP - 1][I] : ex[0][I]);               \
+        const u32 rank = (pk >> ((gi << 3) & 31u)) & 0xffu;                                       \
+        const u32 off = EDSX_CUR(gi) + ((I >= 2) ? rank << 2 : rank);                             \
+        if (byte_at<I>(wv)) {                                                                     \
+            const u32 a = tbase + off, t = tokc[I];                                               \
+            if (I >= 2) lds_put4(a, t);                                                           \
+            else if (I == 0) { lds_put2(a, t); if (lane >= 9u) lds_put1<2>(a, t >> 16); }         \
+            else { lds_put2(a, t); lds_put1<2>(a, t >> 16); if (lane >= 35u) lds_put1<3>(a, t >> 24); } \
+        }                                                                                         \
+        _Pragma("unroll") for (int h = 0; h < NP; h++) {                                          \
+            const u32 lo = tot[h][I] & 0x00ff00ffu, hi = (tot[h][I] >> 8) & 0x00ff00ffu;          \
+            C[2 * h] += (I >= 2) ? lo << 2 : lo;                                                  \
+            C[2 * h + 1] += (I >= 2) ? hi << 2 : hi;                                              \
         }                                                                                         \
     }
-    EDSX_R(0) EDSX_R(1) EDSX_R(2) EDSX_R(3) EDSX_R(4) EDSX_R(5) EDSX_R(6) EDSX_R(7)
-    EDSX_R(8) EDSX_R(9) EDSX_R(10) EDSX_R(11) EDSX_R(12) EDSX_R(13) EDSX_R(14) EDSX_R(15)
-#undef EDSX_R
+    EDSX_B(0) EDSX_B(1) EDSX_B(2) EDSX_B(3) EDSX_B(4) EDSX_B(5) EDSX_B(6) EDSX_B(7)
+    EDSX_B(8) EDSX_B(9) EDSX_B(10) EDSX_B(11) EDSX_B(12) EDSX_B(13) EDSX_B(14)
+#undef EDSX_B
+    {
+        const u32 gi = byte_at<15>(gid);
+        u32 pk = ex15[0];
+#pragma unroll
+        for (int j = 1; j < 2 * NP; j++) pk = ((gi >> 2) == (u32)(j >> 1) && (gi & 1u) == (u32)(j & 1)) ? ex15[j] : pk;
+        const u32 off = EDSX_CUR(gi) + ((pk >> (((gi >> 1) & 1u) * 16u)) & 0xffffu);
+        if (byte_at<15>(wv)) {
+            const u32 a = tbase + off;
+            lds_put4(a, tokc[15]);
+            if (lane >= 39u) lds_put1<4>(a, (u32)',');
+        }
+    }
+#undef EDSX_CUR
     if (lane == 0) {                               // braces last: the closing one replaces the final ','
 #pragma unroll
         for (int g = 0; g < 4 * NP; g++) if ((u32)g < k) { text[gstart[g]] = '{'; text[gend[g] - 1] = '}'; }
@@ -1406,12 +1454,10 @@ __device__ __forceinline__ u32 fast_emit_ids_rows(const uint4& gid_strided, u32 
     return run;
 }
 
-__global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
+__global__ void __launch_bounds__(256, 4) k_emit_variant_fast(FastParams p)
 {
     __shared__ __attribute__((aligned(16))) u64 tok_sh[1024];
-    __shared__ __attribute__((aligned(16))) u64 tok_t[1024];
     __shared__ __attribute__((aligned(16))) uint8_t stage_sh[4][FAST_STAGE];
-    __shared__ __attribute__((aligned(16))) uint8_t xpose_sh[4][1024];
     const MsaView& mv = p.mv;
     if (mv.hdr->status) return;
     const u32 lane = threadIdx.x & 63, wv = uniform32(threadIdx.x >> 6);
@@ -1422,22 +1468,23 @@ __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
         for (int i = (int)nd - 1; i >= 0; i--) { t |= (u64)('0' + v % 10u) << (8 * i); v /= 10u; }
         t |= (u64)',' << (8 * nd);
         tok_sh[r] = t | ((u64)(nd + 1) << 56);
-        tok_t[(r & 15u) * 64u + (r >> 4)] = t | ((u64)(nd + 1) << 56);   // row = lane*16 + i  ->  [i*64 + lane]
     }
     __syncthreads();
     uint8_t* stage = stage_sh[wv];
-    uint8_t* xpose = xpose_sh[wv];
-    uint4 tlv_c;                                   // token lengths of rows lane*16 .. lane*16+15 (0: no such row)
+    // lane constants of the packed-scan emitter: tokens and weights of rows lane, lane+64, ...
+    u32 tokc[16];
+    uint4 wgt;
     {
         uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const u32 r = lane * 16u + j;
-            if (r < mv.S) w[j >> 2] |= (ndigits(r + 1) + 1) << ((j & 3) * 8);
+        for (int i = 0; i < 16; i++) {
+            const u32 r = (u32)i * 64u + lane;
+            tokc[i] = (u32)tok_sh[r];
+            const u32 tl = (u32)(tok_sh[r] >> 56);
+            if (r < mv.S) w[i >> 2] |= ((i < 2 || i == 15) ? tl : 1u) << ((i & 3) * 8);
         }
-        tlv_c = make_uint4(w[0], w[1], w[2], w[3]);
+        wgt = make_uint4(w[0], w[1], w[2], w[3]);
     }
-
     const u64 nseg = *p.nseg_ptr;
     const u64 p0 = mv.vbit(0) ? 0 : 1;
     const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
@@ -1453,68 +1500,75 @@ __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
         r.k = rec[GREC_K];
         return r;
     };
+    // Software pipeline over the wave's segments t, t+nw, t+2nw ...: vmcnt retires in issue order, so a
+    // wait for a prefetched record also waits for every store issued before it.  The record of
+    // segment t+2 is therefore requested first, the id text of segment t is built in LDS (no
+    // global traffic), and only then the wave waits — by now the stores of segment t-1 have had the
+    // whole build phase to retire — and issues the stores of segment t.
     u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + uniform32(threadIdx.x >> 6);
-    Rec rc = load_rec(vi < nvs ? vi : 0);
-    u64 meta = vi < nvs ? uniform64(p.segmeta[2 * vi + p0]) : 0;
-    u64 goff = vi < nvs ? uniform64(p.seds_len[2 * vi + p0]) : 0;     // offsets after the scans
-    u64 eoff = vi < nvs ? uniform64(p.eds_len[2 * vi + p0]) : 0;
+    const u64 v0 = vi < nvs ? vi : 0, v1 = vi + nw < nvs ? vi + nw : v0;
+    Rec rc = load_rec(v0), rc_n = load_rec(v1);
+    u64 meta = uniform64(p.segmeta[2 * v0 + p0]), meta_n = uniform64(p.segmeta[2 * v1 + p0]);
+    u64 goff = uniform64(p.seds_len[2 * v0 + p0]), goff_n = uniform64(p.seds_len[2 * v1 + p0]);   // offsets after the scans
+    u64 eoff = uniform64(p.eds_len[2 * v0 + p0]), eoff_n = uniform64(p.eds_len[2 * v1 + p0]);
+    // nothing may be pending at the loop header, or the wait for it is placed inside the loop
+    asm volatile("" :: "v"(rc.gid.x), "v"(rc.gid.y), "v"(rc.gid.z), "v"(rc.gid.w), "v"(rc.rep), "v"(rc.chr), "v"(rc.k),
+                       "v"(rc_n.gid.x), "v"(rc_n.gid.y), "v"(rc_n.gid.z), "v"(rc_n.gid.w), "v"(rc_n.rep), "v"(rc_n.chr), "v"(rc_n.k));
     while (vi < nvs) {
         const u64 seg = 2 * vi + p0;
-        // everything the next segment needs is requested one iteration ahead
-        const u64 vn = vi + nw < nvs ? vi + nw : vi;
-        const Rec rc_n = load_rec(vn);
-        const u64 meta_n = uniform64(p.segmeta[2 * vn + p0]);
-        const u64 goff_n = uniform64(p.seds_len[2 * vn + p0]);
-        const u64 eoff_n = uniform64(p.eds_len[2 * vn + p0]);
-#ifdef EDSX_DIAG
-        const u64 t_diag = __builtin_amdgcn_s_memtime();
-#endif
+        const u64 v2 = vi + 2 * nw < nvs ? vi + 2 * nw : vi;
+        const Rec rc_nn = load_rec(v2);
+        const u64 meta_v = p.segmeta[2 * v2 + p0];          // same address in every lane; made scalar
+        const u64 goff_v = p.seds_len[2 * v2 + p0];         // only after the wait below
+        const u64 eoff_v = p.eds_len[2 * v2 + p0];
         FastGroups G;
         G.gid = rc.gid; G.k = uniform32(rc.k); G.rep = rc.rep; G.key_lo = rc.chr; G.key_hi = 0; G.sumlen = 0; G.len = 0;
         const bool fast = G.k != 0;
-#ifdef EDSX_DIAG
-        DIAG_STAMP(t_g);
-        u64 t_i = t_g, t_f = t_g;
-#endif
+        u32 n = 0;
+        const u32 sh = (u32)goff & 15u;
         if (fast) {
-            const u32 sh = (u32)goff & 15u;
             uint8_t* text = stage + sh;                    // LDS offset == global offset (mod 16)
-            u32 n;
-            if (G.k <= 4) n = fast_emit_ids_rows<1>(G.gid, G.k, text, xpose, tok_t, tlv_c, lane);
-            else if (G.k <= 8) n = fast_emit_ids_rows<2>(G.gid, G.k, text, xpose, tok_t, tlv_c, lane);
+            if (G.k <= 4) n = fast_emit_ids_cols<1>(G.gid, G.k, text, tokc, wgt, lane);
             else n = fast_emit_ids<0>(G.gid, G.k, text, tok_sh, lane);
-#ifdef EDSX_DIAG
-            { DIAG_STAMP(tt); t_i = tt; }
-#endif
-            // ---- flush LDS -> HBM: aligned 16-byte blocks, byte stores for the ragged ends
-            uint8_t* gdst = p.seds + (goff - sh);          // 16-byte aligned image of `stage`
-            const u32 endo = sh + n;
-            const u32 body0 = sh ? 16u : 0u, body1 = endo & ~15u;
-            if (sh && lane < 16) { u32 o = lane; if (o >= sh && o < endo) gdst[o] = stage[o]; }
-            for (u32 o = body0 + lane * 16u; o + 16u <= body1; o += 1024u)
-                *reinterpret_cast<uint4*>(gdst + o) = *reinterpret_cast<const uint4*>(stage + o);
-            {
-                const u32 t0 = body1 > body0 ? body1 : body0;
-                if (lane < 16) { u32 o = t0 + lane; if (o < endo) gdst[o] = stage[o]; }
-            }
-#ifdef EDSX_DIAG
-            { DIAG_STAMP(tt); t_f = tt; }
-#endif
+        }
+        // the wait for the prefetched record (and with it for the previous segment's stores) goes here
+        asm volatile("" :: "v"(rc_nn.gid.x), "v"(rc_nn.gid.y), "v"(rc_nn.gid.z), "v"(rc_nn.gid.w),
+                           "v"(rc_nn.rep), "v"(rc_nn.chr), "v"(rc_nn.k), "v"(meta_v), "v"(goff_v), "v"(eoff_v));
+        const u64 meta_nn = uniform64(meta_v), goff_nn = uniform64(goff_v), eoff_nn = uniform64(eoff_v);
+        if (fast) {
             // ---- eds: "{" s0 "," s1 ... "}"
             {
                 uint8_t* e = p.eds + eoff;
-                if (lane == 0) e[0] = '{';
-                u32 eo = 1;
                 const u32 ncol = (u32)(meta >> 48) & 0xffu;
                 if (ncol == 1) {                          // lane g holds group g's letter (0 = empty string)
                     const u32 c = lane < G.k ? (u32)G.key_lo : 0u;
                     const u64 nz = ballot64(c != 0);
                     const u32 at = 1 + lane + mbcnt(nz);  // '{' + one separator per earlier group + earlier letters
+                    if (lane == 0) e[0] = '{';
                     if (lane < G.k) {
                         if (c) e[at] = (uint8_t)c;
                         e[at + (c ? 1 : 0)] = (lane + 1 < G.k) ? ',' : '}';
                     }
+                } else if (G.k * ncol <= 64u) {           // lane = (group, column): one load round trip
+                    const u32 g = lane / ncol, c = lane - g * ncol;
+                    const u32 r = (u32)__shfl((int)G.rep, (int)(g < G.k ? g : 0u), 64);
+                    u32 ch = 0;
+                    if (g < G.k) {
+                        const u64 sl = (meta & META_SCATTER) ? mv.slot(p.seg_start[seg] + c) : (meta & META_SLOT) + c;
+                        ch = mv.vc[sl * (u64)mv.Spad + vc_pos(r, mv.Gp)];
+                        if (ch == '-' || ch == '\n') ch = 0;
+                    }
+                    const u64 m = ballot64(ch != 0);
+                    if (lane == 0) e[0] = '{';
+                    if (ch) e[1 + g + mbcnt(m)] = (uint8_t)ch;
+                    if (g < G.k && c == 0) {              // separator after group g's letters
+                        const u32 endl = (g + 1) * ncol;
+                        const u64 upto = endl >= 64u ? ~0ull : ((1ull << endl) - 1);
+                        e[1 + g + (u32)__builtin_popcountll(m & upto)] = (g + 1 < G.k) ? ',' : '}';
+                    }
                 } else {
+                    if (lane == 0) e[0] = '{';
+                    u32 eo = 1;
                     for (u32 g = 0; g < G.k; g++) {       // lane = column: the representative row's letters
                         const u32 r = (u32)__builtin_amdgcn_readlane((int)G.rep, (int)g);
                         u32 ch = 0;
@@ -1531,18 +1585,21 @@ __global__ void __launch_bounds__(256) k_emit_variant_fast(FastParams p)
                     }
                 }
             }
-        }
-#ifdef EDSX_DIAG
-        if (fast) {
-            const u64 t_e = __builtin_amdgcn_s_memtime();
-            diag_add(1, (u32)(meta >> 48) & 0xff, G.k, t_e - t_diag, lane);
-            if (lane == 0 && ((meta >> 48) & 0xff) == 1 && G.k <= 4) {
-                atomicAdd(&g_stage[0], t_g - t_diag); atomicAdd(&g_stage[1], t_i - t_g);
-                atomicAdd(&g_stage[2], t_f - t_i); atomicAdd(&g_stage[3], t_e - t_f);
+            // ---- flush LDS -> HBM: aligned 16-byte blocks, byte stores for the ragged ends
+            uint8_t* gdst = p.seds + (goff - sh);          // 16-byte aligned image of `stage`
+            const u32 endo = sh + n;
+            const u32 body0 = sh ? 16u : 0u, body1 = endo & ~15u;
+            if (sh && lane < 16) { u32 o = lane; if (o >= sh && o < endo) gdst[o] = stage[o]; }
+            for (u32 o = body0 + lane * 16u; o + 16u <= body1; o += 1024u)
+                *reinterpret_cast<uint4*>(gdst + o) = *reinterpret_cast<const uint4*>(stage + o);
+            {
+                const u32 t0 = body1 > body0 ? body1 : body0;
+                if (lane < 16) { u32 o = t0 + lane; if (o < endo) gdst[o] = stage[o]; }
             }
         }
-#endif
-        vi += nw; meta = meta_n; rc = rc_n; goff = goff_n; eoff = eoff_n;
+        vi += nw;
+        rc = rc_n; meta = meta_n; goff = goff_n; eoff = eoff_n;
+        rc_n = rc_nn; meta_n = meta_nn; goff_n = goff_nn; eoff_n = eoff_nn;
     }
 }
 
@@ -1907,27 +1964,6 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
         TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
     }
     EDSX_HIP(hipGetLastError());
-#ifdef EDSX_DIAG
-    {
-        EDSX_HIP(hipStreamSynchronize(st));
-        u64 h[2][8][3];
-        EDSX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof(h)));
-        const char* names[8] = {"1col k<=4", "1col k5-16", "2-8col k<=4", "2-8col k5-16", ">8col k<=4", ">8col k5-16", "<=8col k>16", ">8col k>16"};
-        for (int kk = 0; kk < 2; kk++)
-            for (int c = 0; c < 8; c++)
-                if (h[kk][c][1])
-                    fprintf(stderr, "DIAG %s %-14s n=%llu avg=%llu max=%llu total_Mcyc=%llu\n", kk ? "emit " : "count", names[c],
-                            h[kk][c][1], h[kk][c][0] / h[kk][c][1], h[kk][c][2], h[kk][c][0] / 1000000);
-        u64 stg[8];
-        EDSX_HIP(hipMemcpyFromSymbol(stg, HIP_SYMBOL(g_stage), sizeof(stg)));
-        if (h[1][0][1])
-            fprintf(stderr, "DIAG emit 1col stages avg: group=%llu ids=%llu flush=%llu eds=%llu\n", stg[0] / h[1][0][1],
-                    stg[1] / h[1][0][1], stg[2] / h[1][0][1], stg[3] / h[1][0][1]);
-        memset(h, 0, sizeof(h)); memset(stg, 0, sizeof(stg));
-        EDSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stage), stg, sizeof(stg)));
-        EDSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_diag), h, sizeof(h)));
-    }
-#endif
 }
 
 } // namespace edsx
