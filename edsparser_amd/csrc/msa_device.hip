@@ -345,6 +345,23 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     // extraction: variant bytes -> LDS (column-major) -> HBM, in batches of cap_cols columns
     if (!overflow && nv) {
         const u32 cap = p.cap_cols;
+        // LANEROWS: this thread's 16 rows x 16 columns, transposed in registers with v_perm_b32 (two
+        // rounds of byte interleaves per 4x4 block, 128 instructions): tr[c][k] = column c, rows 4k..4k+3
+        uint32_t tr[(HOLD && LANEROWS) ? 16 : 1][4];
+        if constexpr (HOLD && LANEROWS) {
+#define EDSX_T(C, COMP)                                                                            \
+            _Pragma("unroll") for (int k4 = 0; k4 < 4; k4++) {                                    \
+                const uint32_t a0 = d[4 * k4].COMP, a1 = d[4 * k4 + 1].COMP, a2 = d[4 * k4 + 2].COMP, a3 = d[4 * k4 + 3].COMP; \
+                const uint32_t t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u); \
+                const uint32_t t2 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), t3 = __builtin_amdgcn_perm(a3, a2, 0x07030602u); \
+                tr[4 * C][k4] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);                       \
+                tr[4 * C + 1][k4] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);                   \
+                tr[4 * C + 2][k4] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);                   \
+                tr[4 * C + 3][k4] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);                   \
+            }
+            EDSX_T(0, x) EDSX_T(1, y) EDSX_T(2, z) EDSX_T(3, w)
+#undef EDSX_T
+        }
         for (u32 b0 = 0; b0 < nv; b0 += cap) {
             if (V16) {
                 u32 idx = pre[j];
@@ -354,11 +371,8 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                         if (idx >= b0 && idx < b0 + cap) {                                     \
                             uint8_t* dst = colbuf + (size_t)(idx - b0) * p.Spad;               \
                             if constexpr (LANEROWS) { /* RI == 64, Gp == 16: this thread's 16 rows are 16 */ \
-                                uint32_t w[4];  /* consecutive bytes of the permuted column      */ \
-                                _Pragma("unroll") for (int k4 = 0; k4 < 4; k4++)               \
-                                    w[k4] = byte_at<I>(d[4 * k4]) | (byte_at<I>(d[4 * k4 + 1]) << 8) | \
-                                            (byte_at<I>(d[4 * k4 + 2]) << 16) | (byte_at<I>(d[4 * k4 + 3]) << 24); \
-                                *reinterpret_cast<uint4*>(dst + sub * 16) = make_uint4(w[0], w[1], w[2], w[3]); \
+                                constexpr int TI = LANEROWS ? I : 0; /* consecutive bytes of the permuted column */ \
+                                *reinterpret_cast<uint4*>(dst + sub * 16) = make_uint4(tr[TI][0], tr[TI][1], tr[TI][2], tr[TI][3]); \
                             } else {                                                           \
                                 _Pragma("unroll") for (int it = 0; it < RPT; it++) {           \
                                     const u32 r = sub + it * RI;                               \
