@@ -912,8 +912,8 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
 __device__ __forceinline__ uint32_t bytes_ne_mask(uint32_t a, uint32_t b)   // 0xFF where bytes differ
 {
     uint32_t x = a ^ b;
-    uint32_t t = ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u) >> 7;
-    return t * 0xffu;
+    uint32_t h = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // 0x80 where the bytes differ
+    return h | (h - (h >> 7));              // -> 0xFF; (h >> 7) * 0xff would be a quarter-rate v_mul_lo_u32
 }
 __device__ __forceinline__ uint4 bytes_eq_mask(const uint4& a, uint32_t cccc)
 {
@@ -1010,6 +1010,37 @@ __device__ __forceinline__ bool fast_assign(FastGroups& G, uint4& rm, const uint
     return true;
 }
 
+// signature weights of the multi-column grouping: W_j(c), 24 bit, odd.  A compile-time table (read
+// with scalar loads) instead of two v_mul_lo_u32 per weight.
+struct FastWeights {
+    u32 v[64 * 3];
+    constexpr FastWeights() : v{} {
+        for (u32 c = 0; c < 64; c++)
+            for (u32 j = 0; j < 3; j++) {
+                u32 x = (c + 1u) * 0x9e3779b1u + (j + 1u) * 0x85ebca77u;
+                x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+                v[c * 3 + j] = (x | 1u) & 0xffffffu;
+            }
+    }
+};
+__device__ const FastWeights FAST_W{};
+
+// XOR of v over the 64 lanes, wave-uniform (DPP row shifts and broadcasts; lane 63 ends up with all)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ u32 dpp_move0(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);   // lanes without a source get 0
+}
+__device__ __forceinline__ u32 wave_xor_all(u32 v)
+{
+    v ^= dpp_move0<0x111, 0xf>(v);       // row_shr:1
+    v ^= dpp_move0<0x112, 0xf>(v);       // row_shr:2
+    v ^= dpp_move0<0x114, 0xf>(v);       // row_shr:4
+    v ^= dpp_move0<0x118, 0xf>(v);       // row_shr:8   -> lane 15 of every row: the row's XOR
+    v ^= dpp_move0<0x142, 0xa>(v);       // row_bcast:15 -> rows 1, 3
+    v ^= dpp_move0<0x143, 0xc>(v);       // row_bcast:31 -> rows 2, 3
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Group the rows of a fast segment (msa_transforms.cpp:262-293: distinct gap-stripped strings in
 // order of first appearance).  Returns false when the segment must take the generic path.
 //   one column : exact, SWAR byte compares.
@@ -1051,11 +1082,7 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
     auto col_ptr = [&](u32 c) -> const uint8_t* {
         return scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + (u64)lane * mv.Gp : cbase + (u64)c * mv.Spad;
     };
-    auto weight = [](u32 c, u32 j) -> u32 {
-        u32 x = (c + 1u) * 0x9e3779b1u + (j + 1u) * 0x85ebca77u;
-        x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
-        return (x | 1u) & 0xffffffu;
-    };
+    auto weight = [](u32 c, u32 j) -> u32 { return FAST_W.v[c * 3u + j]; };
 #define EDSX_H(I)                                                                                 \
         {                                                                                         \
             const u32 bch = byte_at<I>(cn);                                                       \
@@ -1112,18 +1139,24 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
         const u64 nzm = ballot64(ch != 0);
         const u32 len = (u32)__builtin_popcountll(nzm);
         const u32 pos = mbcnt(nzm);
+        // key: the first 12 letters verbatim (96 bits: exact for strings up to 12 letters), the
+        // letters behind them hashed on top; the length goes into the key separately
         u32 t1 = 0, t2 = 0, t3 = 0;
-        if (ch) {
-            u32 x = (ch + 1u) * 0x9e3779b1u ^ (pos + 1u) * 0x85ebca77u;
-            x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15;
-            t1 = x * 0x735a2d97u; t1 ^= t1 >> 15;
-            t2 = (x ^ 0x5bd1e995u) * 0xc2b2ae3du; t2 ^= t2 >> 13;
-            t3 = (x + 0x27d4eb2fu) * 0x165667b1u; t3 ^= t3 >> 16;
+        if (ch && pos < 12u) {
+            const u32 v = ch << ((pos & 3u) * 8u), wsel = pos >> 2;
+            t1 = wsel == 0u ? v : 0u; t2 = wsel == 1u ? v : 0u; t3 = wsel == 2u ? v : 0u;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            t1 ^= __shfl_xor(t1, o, 64); t2 ^= __shfl_xor(t2, o, 64); t3 ^= __shfl_xor(t3, o, 64);
+        if (len > 12u) {                                   // wave-uniform
+            if (ch && pos >= 12u) {
+                u32 x = (ch + 1u) * 0x9e3779b1u ^ (pos + 1u) * 0x85ebca77u;
+                x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15;
+                t1 = x * 0x735a2d97u; t1 ^= t1 >> 15;
+                t2 = (x ^ 0x5bd1e995u) * 0xc2b2ae3du; t2 ^= t2 >> 13;
+                t3 = (x + 0x27d4eb2fu) * 0x165667b1u; t3 ^= t3 >> 16;
+            }
         }
-        const u64 klo = ((u64)uniform32(t2) << 32) | uniform32(t1), khi = ((u64)len << 32) | uniform32(t3);
+        t1 = wave_xor_all(t1); t2 = wave_xor_all(t2); t3 = wave_xor_all(t3);
+        const u64 klo = ((u64)t2 << 32) | t1, khi = ((u64)len << 32) | t3;
         if (!fast_assign(G, rm, eq, klo, khi, len, lane, rep_row)) return false;
     }
     return true;
