@@ -110,7 +110,7 @@ int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info)
     const MsaHdr& h = ctx->msa.header();
     info->n_rows = h.S; info->n_cols = h.L; info->line_width = h.lw ? h.lw : h.L;
     info->n_variant_cols = h.nv; info->n_segments = h.nseg; info->msa_bytes = ctx->msa.msa_bytes();
-    info->n_slow_segments = h.slow_n;
+    info->n_slow_segments = h.slow_n + h.slow_n2;
     return EDSX_OK;
 }
 

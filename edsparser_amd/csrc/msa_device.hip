@@ -525,21 +525,52 @@ struct SegLds {
     }
 };
 
-__device__ __forceinline__ u32 seg_col_byte(const MsaView& mv, u64 c, u32 r, u32 isvar, u64 slot)
+// Cells of one segment.  Read from HBM a cell costs a chain of dependent loads (V word, slot table,
+// vc byte); segments of up to STAGE_COLS pure variant columns are first copied into LDS (`st`), which
+// turns the generic kernels' latency-bound row walks into LDS reads.
+constexpr u32 STAGE_COLS = 64;
+struct SegCells {
+    const MsaView& mv; u64 a; const uint8_t* st;
+    __device__ __forceinline__ u32 at(u64 c, u32 r) const
+    {
+        if (st) return st[(size_t)(c - a) * mv.Spad + vc_pos(r, mv.Gp)];
+        return mv.vbit(c) ? mv.vc[mv.slot(c) * mv.Spad + vc_pos(r, mv.Gp)] : mv.ref_byte(c);
+    }
+};
+// all threads of the workgroup; returns the LDS image of the segment's columns or nullptr
+__device__ const uint8_t* stage_columns(const MsaView& mv, u64 a, u64 b, uint8_t* buf, u32 cap_cols, u32* flag_sh)
 {
-    return isvar ? mv.vc[slot * mv.Spad + vc_pos(r, mv.Gp)] : mv.ref_byte(c);
+    const u64 ncol = b - a;
+    if (!buf || ncol > cap_cols) return nullptr;
+    u64* slot_tab = reinterpret_cast<u64*>(buf);              // cap_cols entries, then the columns
+    uint8_t* cols = buf + (size_t)cap_cols * 8;
+    if (threadIdx.x == 0) *flag_sh = 0;
+    __syncthreads();
+    if (threadIdx.x < ncol) {
+        const u64 c = a + threadIdx.x;
+        if (mv.vbit(c)) slot_tab[threadIdx.x] = mv.slot(c);
+        else *flag_sh = 1;                                    // a common column inside (context merge): not staged
+    }
+    __syncthreads();
+    if (*flag_sh) return nullptr;
+    const u32 vec = mv.Spad / 16;                             // Spad % 16 == 0
+    for (u32 i = threadIdx.x; i < (u32)ncol * vec; i += blockDim.x) {
+        const u32 c = i / vec, o = (i - c * vec) * 16;
+        *reinterpret_cast<uint4*>(cols + (size_t)c * mv.Spad + o) =
+            *reinterpret_cast<const uint4*>(mv.vc + slot_tab[c] * (u64)mv.Spad + o);
+    }
+    __syncthreads();
+    return cols;
 }
 
 // gap-stripped string of row r over [a,b): the reference drops '\n' and '-' and stops at '\0'
 // (msa_transforms.cpp:281-286)
-__device__ u64 seg_row_key(const MsaView& mv, u64 a, u64 b, u32 r, bool exact, u32& saw_nl)
+__device__ u64 seg_row_key(const SegCells& sc, u64 a, u64 b, u32 r, bool exact, u32& saw_nl)
 {
     u64 key = exact ? 0ull : 0xcbf29ce484222325ull;
     u32 len = 0;
     for (u64 c = a; c < b; c++) {
-        u32 isvar = mv.vbit(c);
-        u64 sl = isvar ? mv.slot(c) : 0;
-        u32 ch = seg_col_byte(mv, c, r, isvar, sl);
+        u32 ch = sc.at(c, r);
         if (ch == 0) break;
         if (ch == '\n') saw_nl = 1;
         if (ch == '-' || ch == '\n') continue;
@@ -551,21 +582,19 @@ __device__ u64 seg_row_key(const MsaView& mv, u64 a, u64 b, u32 r, bool exact, u
     return key;
 }
 
-__device__ bool seg_rows_equal(const MsaView& mv, u64 a, u64 b, u32 r1, u32 r2)
+__device__ bool seg_rows_equal(const SegCells& sc, u64 a, u64 b, u32 r1, u32 r2)
 {
     u64 c1 = a, c2 = a;
     while (true) {
         u32 x = 0, y = 0;
         while (c1 < b) {
-            u32 isvar = mv.vbit(c1);
-            u32 ch = seg_col_byte(mv, c1, r1, isvar, isvar ? mv.slot(c1) : 0);
+            u32 ch = sc.at(c1, r1);
             if (ch == 0) { c1 = b; break; }
             c1++;
             if (ch != '-' && ch != '\n') { x = ch; break; }
         }
         while (c2 < b) {
-            u32 isvar = mv.vbit(c2);
-            u32 ch = seg_col_byte(mv, c2, r2, isvar, isvar ? mv.slot(c2) : 0);
+            u32 ch = sc.at(c2, r2);
             if (ch == 0) { c2 = b; break; }
             c2++;
             if (ch != '-' && ch != '\n') { y = ch; break; }
@@ -575,12 +604,11 @@ __device__ bool seg_rows_equal(const MsaView& mv, u64 a, u64 b, u32 r1, u32 r2)
     }
 }
 
-__device__ u32 seg_row_len(const MsaView& mv, u64 a, u64 b, u32 r)
+__device__ u32 seg_row_len(const SegCells& sc, u64 a, u64 b, u32 r)
 {
     u32 len = 0;
     for (u64 c = a; c < b; c++) {
-        u32 isvar = mv.vbit(c);
-        u32 ch = seg_col_byte(mv, c, r, isvar, isvar ? mv.slot(c) : 0);
+        u32 ch = sc.at(c, r);
         if (ch == 0) break;
         if (ch != '-' && ch != '\n') len++;
     }
@@ -607,13 +635,14 @@ struct HtLds {
 };
 
 // returns k (number of distinct strings); fills lds.gid[], lds.rep_row[0..k)
-__device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* rep_sh)
+__device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* rep_sh, const uint8_t* st)
 {
     const u32 S = mv.S;
+    const SegCells sc{mv, a, st};
     const bool exact = (b - a) <= 8;
     u32 saw_nl = 0;
     for (u32 r = threadIdx.x; r < S; r += GT) {
-        lds.key[r] = seg_row_key(mv, a, b, r, exact, saw_nl);
+        lds.key[r] = seg_row_key(sc, a, b, r, exact, saw_nl);
         lds.gid[r] = GID_NONE;
     }
     if (saw_nl) atomicOr(&mv.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));   // a row is ragged
@@ -637,7 +666,7 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
         __syncthreads();
         for (u32 r = threadIdx.x; r < S; r += GT) {
             const u32 f = ht.tabm[lds.run[r]];
-            if (!exact && f != r && !seg_rows_equal(mv, a, b, r, f)) *ht.flag = 1;
+            if (!exact && f != r && !seg_rows_equal(sc, a, b, r, f)) *ht.flag = 1;
             lds.rep_row[r] = f;                       // temporarily: first row of r's group
             if (f == r) atomicOr(&ht.bm[r >> 5], 1u << (r & 31));
         }
@@ -689,7 +718,7 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
         const u64 rk = lds.key[rep];
         for (u32 r = cursor; r < S; r += GT) {
             if (lds.gid[r] == GID_NONE && lds.key[r] == rk &&
-                (exact || r == rep || seg_rows_equal(mv, a, b, r, rep)))
+                (exact || r == rep || seg_rows_equal(sc, a, b, r, rep)))
                 lds.gid[r] = (uint16_t)g;
         }
         if (threadIdx.x == 0) lds.rep_row[g] = rep;
@@ -702,6 +731,7 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
 struct SegParams {
     MsaView mv; const u64* seg_start; const u64* nseg_ptr; u64* eds_len; u64* seds_len; u64 tok_total;
     const u64* list; const u64* list_n;       // when set: only these segments (left over by the fast path)
+    u32 stage_cols = 0, stage_off = 0;        // LDS column staging: capacity in columns, byte offset in the dynamic LDS
 };
 
 // K3: per-segment output sizes.  common: "{" ref "}" and "{0}"; variant: see generate_output.
@@ -721,9 +751,11 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
             continue;
         }
         if (threadIdx.x == 0) sum_sh = 0;
-        const u32 k = group_segment(p.mv, a, b, lds, &rep_sh);
+        const uint8_t* st = stage_columns(p.mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, p.stage_cols, &rep_sh);
+        const u32 k = group_segment(p.mv, a, b, lds, &rep_sh, st);
+        const SegCells sc{p.mv, a, st};
         u64 mine = 0;
-        for (u32 g = threadIdx.x; g < k; g += GT) mine += seg_row_len(p.mv, a, b, lds.rep_row[g]);
+        for (u32 g = threadIdx.x; g < k; g += GT) mine += seg_row_len(sc, a, b, lds.rep_row[g]);
         if (mine) atomicAdd(&sum_sh, mine);
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -742,6 +774,7 @@ struct EmitParams {
     MsaView mv; const u64* seg_start; const u64* nseg_ptr; const u64* Hseg; const u64* segbase;
     const u64* eds_off; const u64* seds_off; uint8_t* eds; uint8_t* seds; u64 nwords;
     const u64* list; const u64* list_n;
+    u32 stage_cols = 0, stage_off = 0;
 };
 
 __global__ void __launch_bounds__(256) k_emit_common(EmitParams p)
@@ -791,14 +824,16 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
         const u64 seg = p.list ? p.list[it] : it;
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         if (!mv.vbit(a)) continue;
-        const u32 k = group_segment(mv, a, b, lds, &rep_sh);
+        const uint8_t* st = stage_columns(mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, p.stage_cols, &rep_sh);
+        const u32 k = group_segment(mv, a, b, lds, &rep_sh, st);
+        const SegCells sc{mv, a, st};
         uint8_t* eds = p.eds + p.eds_off[seg];
         uint8_t* seds = p.seds + p.seds_off[seg];
 
         // ---- eds: "{" s0 "," s1 ... "}" ; key[] is reused for the string offsets
         u64* goff = lds.key;
         for (u32 g = threadIdx.x; g < k; g += GT) {
-            goff[g] = seg_row_len(mv, a, b, lds.rep_row[g]);
+            goff[g] = seg_row_len(sc, a, b, lds.rep_row[g]);
             lds.run[g] = 0;
         }
         __syncthreads();
@@ -819,8 +854,7 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
             uint8_t* dst = eds + goff[g];
             const u32 r = lds.rep_row[g];
             for (u64 c = a; c < b; c++) {
-                u32 isvar = mv.vbit(c);
-                u32 ch = seg_col_byte(mv, c, r, isvar, isvar ? mv.slot(c) : 0);
+                u32 ch = sc.at(c, r);
                 if (ch == 0) break;
                 if (ch != '-' && ch != '\n') *dst++ = (uint8_t)ch;
             }
@@ -905,6 +939,7 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
             }
             if (pure) meta = META_FAST | (contig ? 0 : META_SCATTER) | (ncol << 48) | s0;
         }
+        if (!meta) p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;      // too wide for the fast kernels
         p.segmeta[seg] = meta;
     }
 }
@@ -1041,6 +1076,81 @@ __device__ __forceinline__ u32 wave_xor_all(u32 v)
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+__device__ __forceinline__ u32 wave_or_all(u32 v)
+{
+    v |= dpp_move0<0x111, 0xf>(v); v |= dpp_move0<0x112, 0xf>(v); v |= dpp_move0<0x114, 0xf>(v);
+    v |= dpp_move0<0x118, 0xf>(v); v |= dpp_move0<0x142, 0xa>(v); v |= dpp_move0<0x143, 0xc>(v);
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+// minimum of v over lanes 0..7 (wave-uniform)
+__device__ __forceinline__ u32 min_lanes8(u32 v)
+{
+    u32 t;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;
+    return (u32)__builtin_amdgcn_readlane((int)v, 7);
+}
+
+// One column over the alphabet {A, C, G, T, N, -}: the grouping of msa_transforms.cpp:262-293 with
+// byte-table lookups (v_perm_b32 = four lookups in an 8-entry table per instruction).
+//   class(b) = ((b >> 1) ^ (b >> 2)) & 7 :  A 0, C 1, G 2, N 4, '-' 5, T 7  (3 and 6 unused)
+// Any other byte (lower case, IUPAC codes, a stray newline) fails the reverse lookup and the caller
+// takes the general path.  Group ids are the ranks of the classes by first row; the groups' state
+// (representative row, letter) lands in lanes 0..k-1 as in fast_assign.
+__device__ __forceinline__ bool fast_group_dna1(const uint4& x, const uint4& vmask, u32 lane, FastGroups& G)
+{
+    constexpr u32 LET_LO = 0x00474341u, LET_HI = 0x54002d4eu;      // class -> letter (0: unused class)
+    constexpr u32 OH_LO = 0x08040201u, OH_HI = 0x80402010u;        // class -> 1 << class
+    uint4 cls;
+    cls.x = ((x.x >> 1) ^ (x.x >> 2)) & 0x07070707u; cls.y = ((x.y >> 1) ^ (x.y >> 2)) & 0x07070707u;
+    cls.z = ((x.z >> 1) ^ (x.z >> 2)) & 0x07070707u; cls.w = ((x.w >> 1) ^ (x.w >> 2)) & 0x07070707u;
+    const u32 bad = ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.x) ^ x.x) & vmask.x) |
+                    ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.y) ^ x.y) & vmask.y) |
+                    ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.z) ^ x.z) & vmask.z) |
+                    ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.w) ^ x.w) & vmask.w);
+    if (ballot64(bad != 0)) return false;
+    // classes present in the column
+    u32 pl = (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.x) & vmask.x) | (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.y) & vmask.y) |
+             (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.z) & vmask.z) | (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.w) & vmask.w);
+    pl |= pl >> 16; pl |= pl >> 8;
+    const u32 P = wave_or_all(pl & 0xffu);
+    cls.x |= ~vmask.x; cls.y |= ~vmask.y; cls.z |= ~vmask.z; cls.w |= ~vmask.w;   // rows that do not exist: 0xFF
+    // first row of every class: lane c keeps class c's (rows are scanned 64 at a time, in row order)
+    u32 firstv = 0xffffffffu, missing = P;
+#define EDSX_F(I)                                                                                 \
+    if (missing) {                                                                                \
+        const u32 cb = byte_at<I>(cls);                                                           \
+        for (u32 mm = missing; mm; mm &= mm - 1) {                                                \
+            const u32 c = (u32)__builtin_ctz(mm);                                                 \
+            const u64 b = ballot64(cb == c);                                                      \
+            if (b) { firstv = lane == c ? (u32)I * 64u + (u32)__builtin_ctzll(b) : firstv; missing &= ~(1u << c); } \
+        }                                                                                         \
+    }
+    EDSX_F(0) EDSX_F(1) EDSX_F(2) EDSX_F(3) EDSX_F(4) EDSX_F(5) EDSX_F(6) EDSX_F(7)
+    EDSX_F(8) EDSX_F(9) EDSX_F(10) EDSX_F(11) EDSX_F(12) EDSX_F(13) EDSX_F(14) EDSX_F(15)
+#undef EDSX_F
+    // classes in order of first row -> group ids; table class -> group for the lookup below
+    u64 lut = ~0ull;
+    u32 g = 0, sumlen = 0;
+    G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
+    for (u32 rem = P; rem; g++) {
+        const u32 mn = min_lanes8(firstv);
+        const u32 c = (u32)__builtin_ctzll(ballot64(lane < 8u && firstv == mn));
+        const u32 letter = c == 5u ? 0u : (u32)((((u64)LET_HI << 32) | LET_LO) >> (8u * c)) & 0xffu;
+        lut = (lut & ~(0xffull << (8u * c))) | ((u64)g << (8u * c));
+        if (lane == g) { G.key_lo = letter; G.rep = mn; G.len = letter ? 1u : 0u; }
+        sumlen += letter ? 1u : 0u;
+        firstv = lane == c ? 0xffffffffu : firstv;
+        rem &= ~(1u << c);
+    }
+    G.k = g; G.sumlen = sumlen;
+    const u32 lut_lo = (u32)lut, lut_hi = (u32)(lut >> 32);
+    G.gid = make_uint4(__builtin_amdgcn_perm(lut_hi, lut_lo, cls.x), __builtin_amdgcn_perm(lut_hi, lut_lo, cls.y),
+                       __builtin_amdgcn_perm(lut_hi, lut_lo, cls.z), __builtin_amdgcn_perm(lut_hi, lut_lo, cls.w));
+    return true;
+}
+
 // Group the rows of a fast segment (msa_transforms.cpp:262-293: distinct gap-stripped strings in
 // order of first appearance).  Returns false when the segment must take the generic path.
 //   one column : exact, SWAR byte compares.
@@ -1058,6 +1168,9 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
     G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
 
     if (ncol == 1) {
+        if (fast_group_dna1(col0, vmask, lane, G)) return true;
+        G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
+        G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
         const uint4 col = normalise_col<CHECK_NL>(col0, vmask, saw_nl);
         while (ballot64(any4(rm))) {
             int leader;
@@ -1217,7 +1330,7 @@ __global__ void __launch_bounds__(256) k_seg_count_fast(FastParams p)
             }
         } else if (lane == 0) {
             rec[GREC_K] = 0;                              // not a fast segment
-            p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;
+            if (meta & META_FAST) p.slow_list2[atomicAdd(p.slow_count2, 1ull)] = seg;   // gave up: too many strings
         }
         vi += nw; meta = meta_n; meta_n = meta_nn; col = col_n;
     }
@@ -1676,9 +1789,9 @@ void MsaPipeline::launch_timer_end(hipStream_t st)
 // harvest the finished event pairs of the previous call into the per-kernel accumulators
 void MsaPipeline::clear_timers()
 {
-    if (!timed_.empty()) (void)hipEventSynchronize(timed_.back().t1);
     for (auto& t : timed_) {
         float v = 0;
+        (void)hipEventSynchronize(t.t1);
         if (hipEventElapsedTime(&v, t.t0, t.t1) == hipSuccess) {
             bool found = false;
             for (auto& a : acc_) if (a.name == t.name) { a.total_ms += v; a.count++; found = true; break; }
@@ -1889,30 +2002,42 @@ void MsaPipeline::plan_body(hipStream_t st)
     mv_.S = (u32)S; mv_.Spad = Spad; mv_.Gp = vc_rows_per_lane((u32)S);
     seg_start_p_ = seg_start; hseg_p_ = Hseg; segbase_p_ = segbase; nseg_p_ = d_nseg;
     seg_lds_ = (size_t)18 * S + 64 + (S <= HT_MAX_ROWS ? HtLds::BYTES + 16 : 0);
+    seg_lds_ = (seg_lds_ + 15) & ~(size_t)15;
+    stage_off_ = 0;
+    if (S <= 1024) {                                      // room for STAGE_COLS columns of the segment in LDS
+        stage_off_ = (u32)seg_lds_;
+        seg_lds_ += (size_t)STAGE_COLS * 8 + (size_t)STAGE_COLS * Spad;
+    }
 
     const u64 tok_total = token_total((u32)S);
     fast_ = S <= 1024;
     SegParams sp;
     sp.mv = mv_; sp.seg_start = seg_start; sp.nseg_ptr = d_nseg; sp.eds_len = eds_len_.as<u64>();
     sp.seds_len = seds_len_.as<u64>(); sp.tok_total = tok_total; sp.list = nullptr; sp.list_n = nullptr;
+    sp.stage_cols = stage_off_ ? STAGE_COLS : 0; sp.stage_off = stage_off_;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_count),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     if (fast_) {
         segmeta_.ensure(8 * (L + 2));
-        slow_list_.ensure(8 * (L / 2 + 2));
+        // list 1: too wide or mixed segments (k_seg_meta), list 2: those the fast kernel gives up on; together
+        // at most all variant segments (<= L/2 + 1)
+        slow_list_.ensure(8 * (L + 8));
         fp_.mv = mv_; fp_.seg_start = seg_start; fp_.nseg_ptr = d_nseg; fp_.segmeta = segmeta_.as<u64>();
         fp_.eds_len = eds_len_.as<u64>(); fp_.seds_len = seds_len_.as<u64>();
         fp_.slow_list = slow_list_.as<u64>(); fp_.slow_count = &dh->slow_n;
+        fp_.slow_list2 = slow_list_.as<u64>() + (L / 2 + 4); fp_.slow_count2 = &dh->slow_n2;
         fp_.eds = nullptr; fp_.seds = nullptr; fp_.tok_total = tok_total;
         // one record per variant segment; there are at most as many as variant columns
         grec_.ensure(((size_t)vc_cap_cols_ + 2) * 1280);
         fp_.grec = grec_.as<uint8_t>();
-        EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, sizeof(u64), st));
+        EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, 2 * sizeof(u64), st));
         TIMED("k_seg_meta", st, hipLaunchKernelGGL(k_seg_meta, dim3(4096), dim3(256), 0, st, fp_));
         TIMED("k_seg_count_fast", st, hipLaunchKernelGGL(k_seg_count_fast, dim3(persistent_grid(
                   reinterpret_cast<const void*>(k_seg_count_fast), 256, 0)), dim3(256), 0, st, fp_));
-        sp.list = slow_list_.as<u64>(); sp.list_n = &dh->slow_n;
+        sp.list = fp_.slow_list; sp.list_n = fp_.slow_count;
         TIMED("k_seg_count_slow", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
+        sp.list = fp_.slow_list2; sp.list_n = fp_.slow_count2;
+        TIMED("k_seg_count_slow2", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
     } else {
         TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
     }
@@ -1925,13 +2050,16 @@ void MsaPipeline::plan_body(hipStream_t st)
 // workgroups that are resident at once: one persistent workgroup per slot
 unsigned MsaPipeline::persistent_grid(const void* kern, int threads, size_t dyn_lds) const
 {
-    int per_cu = 1, dev = 0;
-    hipDeviceProp_t prop;
+    int per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, dyn_lds) != hipSuccess || per_cu < 1)
         per_cu = 1;
-    int cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    return (unsigned)(cus * per_cu);
+    if (!cus_) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        const_cast<MsaPipeline*>(this)->cus_ = cus;
+    }
+    return (unsigned)(cus_ * per_cu);
 }
 
 unsigned MsaPipeline::seg_grid() const
@@ -1997,17 +2125,21 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
     ep.eds_off = eds_len_.as<u64>(); ep.seds_off = seds_len_.as<u64>(); ep.eds = d_eds; ep.seds = d_seds;
     ep.nwords = h_.nwords;
     ep.list = nullptr; ep.list_n = nullptr;
-    TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
+    ep.stage_cols = stage_off_ ? STAGE_COLS : 0; ep.stage_off = stage_off_;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_emit_variant),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     if (fast_) {
+        TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
         FastParams fp = fp_;
         fp.eds = d_eds; fp.seds = d_seds;
         TIMED("k_emit_variant_fast", st, hipLaunchKernelGGL(k_emit_variant_fast, dim3(persistent_grid(
                   reinterpret_cast<const void*>(k_emit_variant_fast), 256, 0)), dim3(256), 0, st, fp));
-        ep.list = slow_list_.as<u64>(); ep.list_n = &hdr_.as<MsaHdr>()->slow_n;
+        ep.list = fp_.slow_list; ep.list_n = fp_.slow_count;
         TIMED("k_emit_variant_slow", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+        ep.list = fp_.slow_list2; ep.list_n = fp_.slow_count2;
+        TIMED("k_emit_variant_slow2", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
     } else {
+        TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
         TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
     }
     EDSX_HIP(hipGetLastError());

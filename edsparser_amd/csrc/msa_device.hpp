@@ -40,7 +40,8 @@ struct MsaHdr {
     u64 nv;            // variant columns (slot allocator)
     u64 R, nseg, E, Q;
     u64 tmp_total;
-    u64 slow_n;        // variant segments left to the generic (workgroup-per-segment) kernels
+    u64 slow_n;        // variant segments left to the generic (workgroup-per-segment) kernels: by shape
+    u64 slow_n2;       // ... and those the fast kernel gave up on (more than KCAP distinct strings)
 };
 
 // Row order inside one vc column.  Rows are dealt round-robin over the 64 lanes of a wave in
@@ -76,7 +77,8 @@ struct MsaView {
 struct FastParams {
     MsaView mv; const u64* seg_start; const u64* nseg_ptr; u64* segmeta;
     u64* eds_len; u64* seds_len;            // sizes (count pass) == offsets (emit pass, after the scans)
-    u64* slow_list; u64* slow_count;        // variant segments left to the generic kernels
+    u64* slow_list; u64* slow_count;        // variant segments left to the generic kernels (k_seg_meta)
+    u64* slow_list2; u64* slow_count2;      // ... added by k_seg_count_fast
     uint8_t* eds; uint8_t* seds; u64 tok_total;
     uint8_t* grec;                          // grouping records (count -> emit)
 };
@@ -126,8 +128,10 @@ private:
     const u64* seg_start_p_ = nullptr; const u64* hseg_p_ = nullptr; const u64* segbase_p_ = nullptr;
     const u64* nseg_p_ = nullptr;
     size_t seg_lds_ = 0;
+    u32 stage_off_ = 0;           // generic kernels: offset of the column staging area in their LDS (0: none)
     bool fast_ = false;
     FastParams fp_{};
+    int cus_ = 0;
 };
 
 } // namespace edsx
