@@ -582,25 +582,33 @@ __device__ u64 seg_row_key(const SegCells& sc, u64 a, u64 b, u32 r, bool exact, 
     return key;
 }
 
+// Do rows r1 and r2 spell the same gap-stripped string over [a,b)?  Written for a wave whose lanes
+// compare different row pairs: the common case (the two rows are byte-identical) is one pass with no
+// data-dependent branch; otherwise one merged two-pointer loop in which every lane advances at least
+// one of its pointers per iteration (nested skip loops diverge lane by lane: measured 200 K cycles
+// per call on a 32-column segment).
 __device__ bool seg_rows_equal(const SegCells& sc, u64 a, u64 b, u32 r1, u32 r2)
 {
+    u32 diff = 0, seen0 = 0;
+    for (u64 c = a; c < b; c++) {
+        const u32 x = sc.at(c, r1), y = sc.at(c, r2);
+        diff |= x ^ y;
+        seen0 |= (x == 0) | (y == 0);
+    }
+    if (!diff && !seen0) return true;
     u64 c1 = a, c2 = a;
     while (true) {
-        u32 x = 0, y = 0;
-        while (c1 < b) {
-            u32 ch = sc.at(c1, r1);
-            if (ch == 0) { c1 = b; break; }
-            c1++;
-            if (ch != '-' && ch != '\n') { x = ch; break; }
+        u32 x = c1 < b ? sc.at(c1, r1) : 0u, y = c2 < b ? sc.at(c2, r2) : 0u;
+        if (x == 0) c1 = b;                  // '\0' ends the row (msa_transforms.cpp:282)
+        if (y == 0) c2 = b;
+        const bool s1 = x == '-' || x == '\n', s2 = y == '-' || y == '\n';
+        if (s1) c1++;
+        if (s2) c2++;
+        if (!s1 && !s2) {
+            if (x != y) return false;
+            if (x == 0) return true;         // both exhausted
+            c1++; c2++;
         }
-        while (c2 < b) {
-            u32 ch = sc.at(c2, r2);
-            if (ch == 0) { c2 = b; break; }
-            c2++;
-            if (ch != '-' && ch != '\n') { y = ch; break; }
-        }
-        if (x != y) return false;
-        if (x == 0) return true;          // both exhausted
     }
 }
 
@@ -872,22 +880,30 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
                 const u32 tl = ndigits(r + 1) + 1;
                 const u32 tlA = __shfl(tl, 0, 64);              // <= 2 token lengths per 64 rows
                 const u64 maskA = ballot64(valid && tl == tlA);
+                u64 tok = (u64)',' << (8 * (tl - 1));           // "ddd," little-endian: first digit in byte 0
+                { u32 v = r + 1; for (int i = (int)tl - 2; i >= 0; i--) { tok |= (u64)('0' + v % 10u) << (8 * i); v /= 10u; } }
+                // placement: one wave-uniform step per distinct group of the block; the stores follow the
+                // loop, all lanes together (inside it they would run once per group, a few lanes at a time)
+                u32 myoff = 0;
                 u64 todo = ballot64(valid);
                 while (todo) {
                     const int leader = __builtin_ctzll(todo);
-                    const u32 g0 = __shfl(g, leader, 64);
+                    const u32 g0 = (u32)__builtin_amdgcn_readlane((int)g, leader);
                     const u64 m = ballot64(valid && g == g0);
                     const u32 start = lds.run[g0];
-                    if (valid && g == g0) {
-                        const u32 preA = mbcnt(m & maskA), preB = mbcnt(m & ~maskA);
-                        uint8_t* dst = seds + start + preA * tlA + preB * (tlA + 1);
-                        write_decimal(dst, r + 1, tl - 1);
-                        dst[tl - 1] = ',';
-                    }
+                    if (valid && g == g0) myoff = start + mbcnt(m & maskA) * tlA + mbcnt(m & ~maskA) * (tlA + 1);
                     const u32 tot = __builtin_popcountll(m & maskA) * tlA +
                                     __builtin_popcountll(m & ~maskA) * (tlA + 1);
                     if (lane == (u32)leader) lds.run[g0] = start + tot;
                     todo &= ~m;
+                }
+                if (valid) {
+                    uint8_t* dst = seds + myoff;
+                    dst[0] = (uint8_t)tok; dst[1] = (uint8_t)(tok >> 8);
+                    if (tl >= 3) dst[2] = (uint8_t)(tok >> 16);
+                    if (tl >= 4) dst[3] = (uint8_t)(tok >> 24);
+                    if (tl >= 5) dst[4] = (uint8_t)(tok >> 32);
+                    if (tl >= 6) for (u32 i = 5; i < tl; i++) dst[i] = (uint8_t)(tok >> (8 * i));
                 }
             }
             // every store above must have landed before the closing braces overwrite the last ','
