@@ -1501,7 +1501,7 @@ __device__ __forceinline__ u32 fast_emit_ids(const uint4& gid, u32 k, uint8_t* t
     return run;
 }
 
-// ---- id lists, k <= 4*NP: packed prefix sums per block of 64 rows ---------------------------------
+// ---- id lists: packed prefix sums per block of 64 rows, four groups at a time ----------------------
 // Lane `lane` owns rows lane, lane+64, ... (block i = rows i*64 .. i*64+63), exactly as the group ids
 // arrive.  The members of a group inside one block are adjacent in the output, so the lanes of a
 // block store to consecutive LDS addresses (no bank conflicts beyond the overlap of the k groups).
@@ -1529,32 +1529,28 @@ __device__ __forceinline__ u32 wave_scan_incl(u32 v)
     return v;
 }
 
-template <int NP>   // NP = 1: k <= 4, NP = 2: k <= 8
+// Up to four groups (ids 0..3 in `gid`; rows with weight 0 in `wv` are not placed).  Group g's list
+// starts at text + run0 + (lists before it); returns the offset behind the last list.
 __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8_t* text, const u32 (&tokc)[16],
-                                                  const uint4& wv, u32 lane)
+                                                  const uint4& wv, u32 lane, u32 run0)
 {
     const u32 tbase = (u32)(uintptr_t)text;   // LDS byte address (low half of the flat address)
-    u32 ex[NP][15];                // exclusive packed prefix of the row inside its block (8-bit fields)
-    u32 tot[NP][15];               // packed block totals (wave-uniform)
-    u32 ex15[2 * NP], tot15[2 * NP];
-    // byte totals, 16-bit fields: A[2h] = groups 4h (low half) and 4h+2, A[2h+1] = groups 4h+1 and 4h+3
-    u32 A[2 * NP];
-#pragma unroll
-    for (int j = 0; j < 2 * NP; j++) { A[j] = 0; ex15[j] = 0; tot15[j] = 0; }
+    u32 ex[15];                    // exclusive packed prefix of the row inside its block (8-bit fields)
+    u32 tot[15];                   // packed block totals (wave-uniform)
+    u32 ex15[2], tot15[2];
+    // byte totals, 16-bit fields: A[0] = groups 0 (low half) and 2, A[1] = groups 1 and 3
+    u32 A[2] = {0, 0};
 #define EDSX_A(I)                                                                                 \
     {                                                                                             \
         const u32 gi = byte_at<I>(gid);                                                           \
         const u32 f = byte_at<I>(wv) << ((gi << 3) & 31u);                                        \
-        _Pragma("unroll") for (int h = 0; h < NP; h++) {                                          \
-            const u32 fh = NP == 1 ? f : ((gi >> 2) == (u32)h ? f : 0u);                          \
-            const u32 inc = wave_scan_incl(fh);                                                   \
-            ex[h][I] = inc - fh;                                                                  \
-            const u32 t = (u32)__builtin_amdgcn_readlane((int)inc, 63);                           \
-            tot[h][I] = t;                                                                        \
-            const u32 lo = t & 0x00ff00ffu, hi = (t >> 8) & 0x00ff00ffu;                          \
-            A[2 * h] += (I >= 2) ? lo << 2 : lo;                                                  \
-            A[2 * h + 1] += (I >= 2) ? hi << 2 : hi;                                              \
-        }                                                                                         \
+        const u32 inc = wave_scan_incl(f);                                                        \
+        ex[I] = inc - f;                                                                          \
+        const u32 t = (u32)__builtin_amdgcn_readlane((int)inc, 63);                               \
+        tot[I] = t;                                                                               \
+        const u32 lo = t & 0x00ff00ffu, hi = (t >> 8) & 0x00ff00ffu;                              \
+        A[0] += (I >= 2) ? lo << 2 : lo;                                                          \
+        A[1] += (I >= 2) ? hi << 2 : hi;                                                          \
     }
     EDSX_A(0) EDSX_A(1) EDSX_A(2) EDSX_A(3) EDSX_A(4) EDSX_A(5) EDSX_A(6) EDSX_A(7)
     EDSX_A(8) EDSX_A(9) EDSX_A(10) EDSX_A(11) EDSX_A(12) EDSX_A(13) EDSX_A(14)
@@ -1563,8 +1559,8 @@ __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8
         const u32 gi = byte_at<15>(gid);
         const u32 f = byte_at<15>(wv) << (((gi >> 1) & 1u) * 16u);
 #pragma unroll
-        for (int j = 0; j < 2 * NP; j++) {
-            const u32 fj = ((gi >> 2) == (u32)(j >> 1) && (gi & 1u) == (u32)(j & 1)) ? f : 0u;
+        for (int j = 0; j < 2; j++) {
+            const u32 fj = (gi & 1u) == (u32)j ? f : 0u;
             const u32 inc = wave_scan_incl(fj);
             ex15[j] = inc - fj;
             tot15[j] = (u32)__builtin_amdgcn_readlane((int)inc, 63);
@@ -1572,28 +1568,23 @@ __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8
         }
     }
     // group starts, and the packed cursors (same field layout as A)
-    u32 C[2 * NP];
+    u32 C[2] = {0, 0};
+    u32 run = run0, gstart[4], gend[4];
 #pragma unroll
-    for (int j = 0; j < 2 * NP; j++) C[j] = 0;
-    u32 run = 0, gstart[4 * NP], gend[4 * NP];
-#pragma unroll
-    for (int g = 0; g < 4 * NP; g++) {
+    for (int g = 0; g < 4; g++) {
         gstart[g] = run;
         if ((u32)g < k) {
-            const int j = 2 * (g >> 2) + (g & 1), sh = 16 * ((g >> 1) & 1);
+            const int j = g & 1, sh = 16 * (g >> 1);
             C[j] |= (run + 1) << sh;
             run += 1 + ((A[j] >> sh) & 0xffffu);
         }
         gend[g] = run;
     }
-#define EDSX_CUR(gi) ((NP == 1 ? ((gi & 1u) ? C[1] : C[0])                                         \
-                               : ((gi & 4u) ? ((gi & 1u) ? C[2 * NP - 1] : C[2 * NP - 2]) : ((gi & 1u) ? C[1] : C[0]))) \
-                      >> (((gi >> 1) & 1u) * 16u) & 0xffffu)
+#define EDSX_CUR(gi) ((((gi & 1u) ? C[1] : C[0]) >> (((gi >> 1) & 1u) * 16u)) & 0xffffu)
 #define EDSX_B(I)                                                                                 \
     {                                                                                             \
         const u32 gi = byte_at<I>(gid);                                                           \
-        const u32 pk = NP == 1 ? ex[0][I] : ((gi & 4u) ? ex[NP - 1][I] : ex[0][I]);               \
-        const u32 rank = (pk >> ((gi << 3) & 31u)) & 0xffu;                                       \
+        const u32 rank = (ex[I] >> ((gi << 3) & 31u)) & 0xffu;                                    \
         const u32 off = EDSX_CUR(gi) + ((I >= 2) ? rank << 2 : rank);                             \
         if (byte_at<I>(wv)) {                                                                     \
             const u32 a = tbase + off, t = tokc[I];                                               \
@@ -1601,20 +1592,16 @@ __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8
             else if (I == 0) { lds_put2(a, t); if (lane >= 9u) lds_put1<2>(a, t >> 16); }         \
             else { lds_put2(a, t); lds_put1<2>(a, t >> 16); if (lane >= 35u) lds_put1<3>(a, t >> 24); } \
         }                                                                                         \
-        _Pragma("unroll") for (int h = 0; h < NP; h++) {                                          \
-            const u32 lo = tot[h][I] & 0x00ff00ffu, hi = (tot[h][I] >> 8) & 0x00ff00ffu;          \
-            C[2 * h] += (I >= 2) ? lo << 2 : lo;                                                  \
-            C[2 * h + 1] += (I >= 2) ? hi << 2 : hi;                                              \
-        }                                                                                         \
+        const u32 lo = tot[I] & 0x00ff00ffu, hi = (tot[I] >> 8) & 0x00ff00ffu;                    \
+        C[0] += (I >= 2) ? lo << 2 : lo;                                                          \
+        C[1] += (I >= 2) ? hi << 2 : hi;                                                          \
     }
     EDSX_B(0) EDSX_B(1) EDSX_B(2) EDSX_B(3) EDSX_B(4) EDSX_B(5) EDSX_B(6) EDSX_B(7)
     EDSX_B(8) EDSX_B(9) EDSX_B(10) EDSX_B(11) EDSX_B(12) EDSX_B(13) EDSX_B(14)
 #undef EDSX_B
     {
         const u32 gi = byte_at<15>(gid);
-        u32 pk = ex15[0];
-#pragma unroll
-        for (int j = 1; j < 2 * NP; j++) pk = ((gi >> 2) == (u32)(j >> 1) && (gi & 1u) == (u32)(j & 1)) ? ex15[j] : pk;
+        const u32 pk = (gi & 1u) ? ex15[1] : ex15[0];
         const u32 off = EDSX_CUR(gi) + ((pk >> (((gi >> 1) & 1u) * 16u)) & 0xffffu);
         if (byte_at<15>(wv)) {
             const u32 a = tbase + off;
@@ -1625,7 +1612,25 @@ __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8
 #undef EDSX_CUR
     if (lane == 0) {                               // braces last: the closing one replaces the final ','
 #pragma unroll
-        for (int g = 0; g < 4 * NP; g++) if ((u32)g < k) { text[gstart[g]] = '{'; text[gend[g] - 1] = '}'; }
+        for (int g = 0; g < 4; g++) if ((u32)g < k) { text[gstart[g]] = '{'; text[gend[g] - 1] = '}'; }
+    }
+    return run;
+}
+
+// More than four groups (k <= 16): four at a time.  The group ids outside the current quartet get
+// weight 0 (SWAR: a byte is inside iff (id ^ base) & 0xFC == 0), the ids inside become 0..3.
+__device__ __forceinline__ u32 fast_emit_ids_cols_multi(const uint4& gid, u32 k, uint8_t* text, const u32 (&tokc)[16],
+                                                        const uint4& wv, u32 lane)
+{
+    u32 run = 0;
+    for (u32 gb = 0; gb < k; gb += 4) {
+        const u32 bb = gb * 0x01010101u;
+        uint4 g2, w2;
+#define EDSX_Q(C)                                                                                 \
+        { const u32 x = gid.C ^ bb; g2.C = x & 0x03030303u; w2.C = wv.C & ~bytes_ne_mask(x & 0xfcfcfcfcu, 0u); }
+        EDSX_Q(x) EDSX_Q(y) EDSX_Q(z) EDSX_Q(w)
+#undef EDSX_Q
+        run = fast_emit_ids_cols(g2, k - gb < 4u ? k - gb : 4u, text, tokc, w2, lane, run);
     }
     return run;
 }
@@ -1704,7 +1709,8 @@ __global__ void __launch_bounds__(256, 4) k_emit_variant_fast(FastParams p)
         const u32 sh = (u32)goff & 15u;
         if (fast) {
             uint8_t* text = stage + sh;                    // LDS offset == global offset (mod 16)
-            if (G.k <= 4) n = fast_emit_ids_cols<1>(G.gid, G.k, text, tokc, wgt, lane);
+            if (G.k <= 4) n = fast_emit_ids_cols(G.gid, G.k, text, tokc, wgt, lane, 0u);
+            else if (G.k <= 16) n = fast_emit_ids_cols_multi(G.gid, G.k, text, tokc, wgt, lane);
             else n = fast_emit_ids<0>(G.gid, G.k, text, tok_sh, lane);
         }
         // the wait for the prefetched record (and with it for the previous segment's stores) goes here
