@@ -121,9 +121,22 @@ __global__ void k_index_rows(const uint8_t* __restrict__ f, u64 n, MsaHdr* h,
         wrapped = 1;
         if (L == 0 || (L - 1) / lw != nlines - 1) { if (lane == 0) h->status |= ST_LAYOUT; return; }
     }
-    u64 p = 0, s = 0, bad = 0;
+    // One dependent load per row: the 64-byte window at q = end of the previous row's data holds that
+    // row's final newline, the next header's '>' and (headers are short) the header's newline.
+    u64 s = 0, bad = 0;
+    u64 st = start0;                                   // row 0: its header was found by k_find_hdr_end
     while (true) {
-        if (f[p] != '>') {
+        if (st + Draw > n) { bad = ST_LAYOUT; break; }
+        if (s >= row_cap) { bad = ST_TOO_MANY_ROWS; break; }
+        if (lane == 0) row_start[s] = st;
+        s++;
+        const u64 q = st + Draw;
+        if (q == n) break;                             // no trailing newline (SURVEY quirk 6)
+        const u32 c = q + lane < n ? f[q + lane] : 0x100u;
+        if ((u32)__builtin_amdgcn_readlane((int)c, 0) != '\n') { bad = ST_LAYOUT; break; }
+        const u64 p = q + 1;
+        if (p == n) break;
+        if ((u32)__builtin_amdgcn_readlane((int)c, 1) != '>') {
             // tolerate blank lines at the very end (skipped by the reference, :47-49)
             u64 rest = n - p;
             if (rest > 4096) { bad = ST_LAYOUT; break; }
@@ -133,22 +146,17 @@ __global__ void k_index_rows(const uint8_t* __restrict__ f, u64 n, MsaHdr* h,
             break;
         }
         u64 nlpos = n;
-        for (u64 base = p; base < n; base += 64) {
-            u64 i = base + lane;
-            u64 b = ballot64(i < n && f[i] == '\n');
-            if (b) { nlpos = base + __builtin_ctzll(b); break; }
+        u64 b = ballot64(lane >= 2 && c == '\n');
+        if (b) nlpos = q + __builtin_ctzll(b);
+        else {
+            for (u64 base = q + 64; base < n; base += 64) {          // a header longer than the window
+                const u64 i = base + lane;
+                b = ballot64(i < n && f[i] == '\n');
+                if (b) { nlpos = base + __builtin_ctzll(b); break; }
+            }
         }
         if (nlpos >= n) { bad = ST_LAYOUT; break; }
-        u64 st = nlpos + 1;
-        if (st + Draw > n) { bad = ST_LAYOUT; break; }
-        if (s >= row_cap) { bad = ST_TOO_MANY_ROWS; break; }
-        if (lane == 0) row_start[s] = st;
-        s++;
-        u64 q = st + Draw;
-        if (q == n) break;                             // no trailing newline (SURVEY quirk 6)
-        if (f[q] != '\n') { bad = ST_LAYOUT; break; }
-        p = q + 1;
-        if (p == n) break;
+        st = nlpos + 1;
     }
     if (lane == 0) {
         if (s < 2 && !bad) bad = ST_FEW_ROWS;
