@@ -1207,18 +1207,85 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
         return true;
     }
 
-    // ---- phase A: raw signatures of the 16 rows of this lane: sig_j(row) = sum_c byte(row,c) * W_j(c)
-    // (gaps are 0 and contribute nothing; v_mad_u32_u24 is full rate).  Rows with equal normalised
-    // columns get equal signatures; different rows collide with probability ~2^-96.
-    u32 h1[16], h2[16], h3[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { h1[i] = 0; h2[i] = 0; h3[i] = 0; }
     const u64 slot0 = meta & META_SLOT;
     const bool scatter = (meta & META_SCATTER) != 0;
     const uint8_t* cbase = mv.vc + slot0 * (u64)mv.Spad + (u64)lane * mv.Gp;
     auto col_ptr = [&](u32 c) -> const uint8_t* {
         return scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + (u64)lane * mv.Gp : cbase + (u64)c * mv.Spad;
     };
+
+    // ---- up to 10 columns over {A,C,G,T,N,-}: EXACT raw keys, 3 bits per column (class code of
+    // fast_group_dna1), one dword per row.  Rows with equal keys are byte-identical; a raw group's
+    // gap-stripped string is read off its key (drop the gap classes), so no row is re-read.
+    if (ncol <= 10u) {
+        constexpr u32 LET_LO = 0x00474341u, LET_HI = 0x54002d4eu;
+        u32 key[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) key[i] = 0;
+        u32 badacc = 0;
+#define EDSX_K(I) key[I] |= byte_at<I>(cls) << sh;
+        for (u32 c0 = 0; c0 < ncol; c0 += 4) {
+            uint4 cvs[4];                              // four column loads in flight
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cvs[j] = make_uint4(0, 0, 0, 0);
+                if (c0 + j < ncol) cvs[j] = (c0 + j == 0) ? col0 : load16u(col_ptr(c0 + j));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (c0 + j < ncol) {
+                    const uint4 x = cvs[j];
+                    uint4 cls;
+                    cls.x = ((x.x >> 1) ^ (x.x >> 2)) & 0x07070707u; cls.y = ((x.y >> 1) ^ (x.y >> 2)) & 0x07070707u;
+                    cls.z = ((x.z >> 1) ^ (x.z >> 2)) & 0x07070707u; cls.w = ((x.w >> 1) ^ (x.w >> 2)) & 0x07070707u;
+                    badacc |= ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.x) ^ x.x) & vmask.x) |
+                              ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.y) ^ x.y) & vmask.y) |
+                              ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.z) ^ x.z) & vmask.z) |
+                              ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.w) ^ x.w) & vmask.w);
+                    const u32 sh = 3u * (c0 + j);
+                    EDSX_K(0) EDSX_K(1) EDSX_K(2) EDSX_K(3) EDSX_K(4) EDSX_K(5) EDSX_K(6) EDSX_K(7)
+                    EDSX_K(8) EDSX_K(9) EDSX_K(10) EDSX_K(11) EDSX_K(12) EDSX_K(13) EDSX_K(14) EDSX_K(15)
+                }
+            }
+        }
+#undef EDSX_K
+        if (!ballot64(badacc != 0)) {
+            while (ballot64(any4(rm))) {
+                int leader;
+                const u32 i0 = first_remaining(rm, leader);
+                u32 mk = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) mk = (i0 == (u32)i) ? key[i] : mk;
+                const u32 rk = (u32)__builtin_amdgcn_readlane((int)mk, leader);
+                uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (key[i] == rk) e0 |= 0xffu << (i * 8);
+                    if (key[i + 4] == rk) e1 |= 0xffu << (i * 8);
+                    if (key[i + 8] == rk) e2 |= 0xffu << (i * 8);
+                    if (key[i + 12] == rk) e3 |= 0xffu << (i * 8);
+                }
+                const uint4 eq = make_uint4(e0 & rm.x, e1 & rm.y, e2 & rm.z, e3 & rm.w);
+                // the group's string: its key without the gap classes (wave-uniform scalar work)
+                u64 sk = 0;
+                u32 len = 0;
+                for (u32 c = 0; c < ncol; c++) {
+                    const u32 cl = (rk >> (3u * c)) & 7u;
+                    if (cl != 5u) { sk |= (u64)cl << (3u * len); len++; }
+                }
+                if (!fast_assign(G, rm, eq, sk, (u64)len << 32, len, lane, i0 * 64u + (u32)leader)) return false;
+            }
+            return true;
+        }
+        rm = vmask;                                    // another alphabet: the signature path below
+    }
+
+    // ---- phase A: raw signatures of the 16 rows of this lane: sig_j(row) = sum_c byte(row,c) * W_j(c)
+    // (gaps are 0 and contribute nothing; v_mad_u32_u24 is full rate).  Rows with equal normalised
+    // columns get equal signatures; different rows collide with probability ~2^-96.
+    u32 h1[16], h2[16], h3[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { h1[i] = 0; h2[i] = 0; h3[i] = 0; }
     auto weight = [](u32 c, u32 j) -> u32 { return FAST_W.v[c * 3u + j]; };
 #define EDSX_H(I)                                                                                 \
         {                                                                                         \
@@ -1310,7 +1377,7 @@ __device__ __forceinline__ uint4 fast_load_col(const MsaView& mv, u64 meta, u32 
 
 // K3 fast: sizes of the variant segments.  Variant and common segments alternate, so the
 // variant ones are seg = 2*vi + p0.
-__global__ void __launch_bounds__(256) k_seg_count_fast(FastParams p)
+__global__ void __launch_bounds__(256, 4) k_seg_count_fast(FastParams p)
 {
     const MsaView& mv = p.mv;
     if (mv.hdr->status) return;
