@@ -217,7 +217,6 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     __shared__ u32 pre[256];
     __shared__ u32 wtot[4];
     __shared__ u64 slot_base_sh;
-    __shared__ u32 nv_sh;
 
     const u32 tid = threadIdx.x;
     const u32 cpr = 1u << p.cpr_log2;
@@ -323,35 +322,21 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
         pre[tid] = incl - c;
     }
     __syncthreads();
-    if (tid < 256) {
-        u32 off = 0;
-        for (u32 w = 0; w < (tid >> 6); w++) off += wtot[w];
-        pre[tid] += off;
-    }
-    if (tid == 0) {
-        u32 nv = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        nv_sh = nv;
-        u64 base = nv ? atomicAdd(&p.hdr->nv, (u64)nv) : 0;
-        slot_base_sh = base;
-        if (base + nv > p.vc_cap_cols) atomicOr(&p.hdr->status, (u64)ST_VC_OVERFLOW);
-    }
-    __syncthreads();
-    const u64 slot_base = slot_base_sh;
-    const u32 nv = nv_sh;
-    const bool overflow = slot_base + nv > p.vc_cap_cols;
-
-    if (tid < cpr / 4) {                                       // V words + per-word slot base
-        u64 wi = q0 / 64 + tid;
-        if (wi * 64 < p.Draw) {
-            u64 bits = (u64)D[4 * tid] | ((u64)D[4 * tid + 1] << 16) | ((u64)D[4 * tid + 2] << 32) |
-                       ((u64)D[4 * tid + 3] << 48);
-            p.Vraw[wi] = bits;
-            p.word_slot[wi] = slot_base + pre[4 * tid];
-        }
-    }
+    // every thread completes its own prefix (no third barrier); the slot atomic is issued now and its
+    // result is first needed after the extraction into LDS, which hides its ~1 us round trip
+    const u32 w0 = wtot[0], w1 = wtot[1], w2 = wtot[2], w3 = wtot[3];
+    const u32 nv = w0 + w1 + w2 + w3;
+    auto pre_of = [&](u32 chunk) -> u32 {
+        const u32 cw = chunk >> 6;
+        return pre[chunk] + (cw > 0 ? w0 : 0u) + (cw > 1 ? w1 : 0u) + (cw > 2 ? w2 : 0u);
+    };
+    u64 base_r = 0;
+    if (tid == 0 && nv) base_r = atomicAdd(&p.hdr->nv, (u64)nv);
 
     // extraction: variant bytes -> LDS (column-major) -> HBM, in batches of cap_cols columns
-    if (!overflow && nv) {
+    u64 slot_base = 0;
+    bool overflow = false;
+    {
         const u32 cap = p.cap_cols;
         // LANEROWS: this thread's 16 rows x 16 columns, transposed in registers with v_perm_b32 (two
         // rounds of byte interleaves per 4x4 block, 128 instructions): tr[c][k] = column c, rows 4k..4k+3
@@ -370,9 +355,9 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
             EDSX_T(0, x) EDSX_T(1, y) EDSX_T(2, z) EDSX_T(3, w)
 #undef EDSX_T
         }
-        for (u32 b0 = 0; b0 < nv; b0 += cap) {
-            if (V16) {
-                u32 idx = pre[j];
+        for (u32 b0 = 0; b0 < nv || b0 == 0; b0 += cap) {
+            if (V16 && nv) {
+                u32 idx = pre_of(j);
                 if constexpr (HOLD) {
 #define EDSX_X(I)                                                                              \
                     if (V16 & (1u << I)) {                                                     \
@@ -414,13 +399,31 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                     }
                 }
             }
+            if (b0 == 0 && tid == 0) {                         // first use of the atomic's result
+                slot_base_sh = base_r;
+                if (base_r + nv > p.vc_cap_cols) atomicOr(&p.hdr->status, (u64)ST_VC_OVERFLOW);
+            }
             __syncthreads();
+            if (b0 == 0) {
+                slot_base = slot_base_sh;
+                overflow = slot_base + nv > p.vc_cap_cols;
+                if (tid < cpr / 4) {                           // V words + per-word slot base
+                    u64 wi = q0 / 64 + tid;
+                    if (wi * 64 < p.Draw) {
+                        u64 bits = (u64)D[4 * tid] | ((u64)D[4 * tid + 1] << 16) | ((u64)D[4 * tid + 2] << 32) |
+                                   ((u64)D[4 * tid + 3] << 48);
+                        p.Vraw[wi] = bits;
+                        p.word_slot[wi] = slot_base + pre_of(4 * tid);
+                    }
+                }
+            }
+            if (!nv || overflow) break;                        // workgroup-uniform
             const u32 ncols = (nv - b0) < cap ? (nv - b0) : cap;
             const size_t nbytes = (size_t)ncols * p.Spad;      // Spad % 16 == 0
             uint8_t* g = p.vc + (slot_base + b0) * (u64)p.Spad;
             for (size_t o = (size_t)tid * 16; o < nbytes; o += (size_t)T * 16)
                 *reinterpret_cast<uint4*>(g + o) = *reinterpret_cast<const uint4*>(colbuf + o);
-            __syncthreads();
+            if (b0 + cap < nv) __syncthreads();                // colbuf is reused by the next batch
         }
     }
     if (bad) atomicOr(&p.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));
