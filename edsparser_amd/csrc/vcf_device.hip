@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstring>
 #include <sstream>
+#include <thread>
 
 namespace edsx {
 
@@ -463,22 +464,57 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
             seq_size += line.size();
         }
     }
-    // ---- VCF records (:690-712) and the unstable sort (:715-718)
+    // ---- VCF records (:690-712) and the unstable sort (:715-718).  Lines are independent: large files
+    // are cut at line starts and tokenised by several host threads; records, counters and the stderr
+    // warnings are put together in file order, so the array handed to std::sort is the reference's.
     std::vector<HostVariant> vars;
     {
-        size_t pos = 0;
-        std::string line, warn;
-        while (next_line(vcf, vcf_n, pos, line)) {
-            Skip skip;
-            HostVariant v;
-            const bool ok = parse_line(line, skip, v, warn);
-            if (skip == Skip::NONE) { stats.total_variants++; stats.processed_variants++; }
-            else if (skip == Skip::MALFORMED) { stats.total_variants++; stats.skipped_malformed++; }
-            else if (skip == Skip::UNSUPPORTED_SV) {
-                stats.total_variants++; stats.skipped_unsupported_sv++;
-                fprintf(stderr, "%s\n", warn.c_str());       // the reference warns on stderr (:301-302)
+        struct Part { std::vector<HostVariant> vars; VcfCounters st; std::vector<std::string> warns; };
+        auto parse_range = [&](size_t lo, size_t hi, Part& out) {
+            size_t pos = lo;
+            std::string line, warn;
+            while (pos < hi && next_line(vcf, vcf_n, pos, line)) {
+                Skip skip;
+                HostVariant v;
+                const bool ok = parse_line(line, skip, v, warn);
+                if (skip == Skip::NONE) { out.st.total_variants++; out.st.processed_variants++; }
+                else if (skip == Skip::MALFORMED) { out.st.total_variants++; out.st.skipped_malformed++; }
+                else if (skip == Skip::UNSUPPORTED_SV) {
+                    out.st.total_variants++; out.st.skipped_unsupported_sv++;
+                    out.warns.push_back(warn);
+                }
+                if (ok) out.vars.push_back(std::move(v));
             }
-            if (ok) vars.push_back(std::move(v));
+        };
+        unsigned nt = 1;
+        if (vcf_n >= ((size_t)4 << 20)) {
+            const unsigned hc = std::thread::hardware_concurrency();
+            nt = std::max(1u, std::min(16u, hc ? hc : 4u));
+        }
+        std::vector<size_t> cut(nt + 1, vcf_n);
+        cut[0] = 0;
+        for (unsigned t = 1; t < nt; t++) {                    // first line start at or after t*n/nt
+            size_t g = (size_t)((unsigned __int128)vcf_n * t / nt);
+            if (g < cut[t - 1]) g = cut[t - 1];
+            const uint8_t* nl = g < vcf_n ? static_cast<const uint8_t*>(memchr(vcf + g, '\n', vcf_n - g)) : nullptr;
+            cut[t] = nl ? static_cast<size_t>(nl - vcf) + 1 : vcf_n;
+            if (g == 0) cut[t] = 0;                            // position 0 is a line start itself
+        }
+        std::vector<Part> parts(nt);
+        if (nt == 1) parse_range(0, vcf_n, parts[0]);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { parse_range(cut[t], cut[t + 1], parts[t]); });
+            for (auto& x : th) x.join();
+        }
+        size_t total = 0;
+        for (auto& pt : parts) total += pt.vars.size();
+        vars.reserve(total);
+        for (auto& pt : parts) {
+            stats.total_variants += pt.st.total_variants; stats.processed_variants += pt.st.processed_variants;
+            stats.skipped_malformed += pt.st.skipped_malformed; stats.skipped_unsupported_sv += pt.st.skipped_unsupported_sv;
+            for (const auto& w : pt.warns) fprintf(stderr, "%s\n", w.c_str());   // the reference warns on stderr (:301-302)
+            for (auto& v : pt.vars) vars.push_back(std::move(v));
         }
         std::sort(vars.begin(), vars.end(), [](const HostVariant& a, const HostVariant& b) { return a.pos < b.pos; });
     }

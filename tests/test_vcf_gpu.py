@@ -87,3 +87,18 @@ def test_random_larger_inputs_vs_oracle(ctx, L, nvar, ns, lw, l):
     except o.OracleError as ex:
         want = {"error": str(ex)}
     assert _run(ctx, vcf, fasta, l) == want
+
+
+def test_multithreaded_tokeniser_large_vcf(ctx):
+    """VCF files of 4 MB and more are cut at line starts and tokenised by several host threads;
+    records, counters and group order must still equal the oracle's (which reads line by line).
+    The file also carries malformed lines and unsupported structural variants across the cuts."""
+    rng = random.Random(99)
+    vcf, fasta = _random_vcf(rng, 400000, 40000, 24, 60)
+    lines = vcf.decode().split("\n")
+    for i in range(200, len(lines) - 1, 997):
+        lines.insert(i, "chr1\tnot_a_number" if i % 2 else "chr1\t%d\t.\tA\t<INV>\t.\tPASS\t." % (i % 4000 + 1))
+    vcf = "\n".join(lines).encode()
+    assert len(vcf) >= 4 << 20
+    e, s, st = o.vcf(vcf, fasta, 0)
+    assert _run(ctx, vcf, fasta, 0) == {"eds": e.decode(), "seds": s.decode(), "stats": st}
