@@ -103,6 +103,100 @@ __global__ void __launch_bounds__(1024) k_find_row0(const uint8_t* __restrict__ 
 }
 
 // one wave: geometry + the chain of row starts (each row start depends on the previous header).
+// ---- speculative parallel row index -------------------------------------------------------------
+// The chain in k_index_rows costs one dependent HBM load per row (~0.65 us).  Rows have equal data
+// length and headers of nearly equal length, so header r is close to r * (distance of the first two
+// headers): one wave per row searches a window around that guess for "\n>" (radius 64 + 8 r bytes,
+// less than half a row), k_index_check then verifies that the found headers chain EXACTLY as the
+// serial walk would see them (every header starts right behind the previous row's data and newline,
+// the file ends after the last row).  Only then is the result published; otherwise (short rows,
+// headers of very different lengths, anything odd) k_index_rows walks the chain as before.
+constexpr u64 IDX_NONE = ~0ull;
+__device__ __forceinline__ u32 chunk_eq16(const uint4& a, uint32_t cccc);   // 16-bit mask: bytes equal to c
+__global__ void __launch_bounds__(256) k_index_spec(const uint8_t* __restrict__ f, u64 n, const MsaHdr* h,
+                                                    u64* __restrict__ hpos, u64* __restrict__ cand, u64 row_cap)
+{
+    if (h->status || h->first_hdr2 >= n) return;
+    const u32 lane = threadIdx.x & 63;
+    const u64 start0 = h->hdr_end + 1;
+    const u64 Draw = h->first_hdr2 - start0;
+    const u64 stride0 = h->first_hdr2 + 1;                     // header 0 -> header 1
+    const u64 rmax = std::min<u64>(row_cap, n / (Draw + 3) + 2);
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 r = 1 + wave; r < rmax; r += nwaves) {
+        u64 found = IDX_NONE, st = IDX_NONE;
+        const u64 g = r * stride0, rad = 64 + 8 * r;
+        if (2 * rad + 128 < Draw && g < n + rad) {
+            const u64 lo = g > rad ? g - rad : 1, hi = std::min<u64>(g + rad, n);
+            u32 cnt = 0;
+            for (u64 base = lo; base < hi; base += 1024) {         // 16 positions per lane and step
+                const u64 i = base + (u64)lane * 16;
+                u32 m = 0;
+                if (i + 16 <= hi) {
+                    const uint4 v = load16u(f + i);
+                    const u32 gt = chunk_eq16(v, 0x3e3e3e3eu), nl = chunk_eq16(v, 0x0a0a0a0au);
+                    m = gt & ((nl << 1) | (f[i - 1] == '\n' ? 1u : 0u)) & 0xffffu;
+                } else {
+                    for (u64 q = i; q < hi; q++) if (f[q] == '>' && f[q - 1] == '\n') m |= 1u << (q - i);
+                }
+                const u64 b = ballot64(m != 0);
+                if (b) {
+                    const int l0 = __builtin_ctzll(b);
+                    const u32 m0 = (u32)__builtin_amdgcn_readlane((int)m, l0);
+                    found = base + (u64)l0 * 16 + (u64)__builtin_ctz(m0);
+                    u32 c = (u32)__builtin_popcount(m);
+                    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+                    cnt += c;
+                }
+            }
+            if (cnt != 1) found = cnt ? IDX_NONE - 1 : IDX_NONE;   // ambiguous / none
+            else {
+                for (u64 base = found; base < std::min<u64>(found + 4096, n); base += 64) {
+                    const u64 i = base + lane;
+                    const u64 b = ballot64(i < n && f[i] == '\n');
+                    if (b) { st = base + (u64)__builtin_ctzll(b) + 1; break; }
+                }
+            }
+        }
+        if (lane == 0) { hpos[r] = found; cand[r] = st; }
+    }
+}
+// one workgroup: link checks in parallel, then thread 0 decides
+__global__ void __launch_bounds__(1024) k_index_check(const uint8_t* __restrict__ f, u64 n, MsaHdr* h,
+                                                      const u64* __restrict__ hpos, const u64* __restrict__ cand,
+                                                      u64* __restrict__ row_start, u64 row_cap)
+{
+    __shared__ u64 first_bad;
+    if (h->status || h->first_hdr2 >= n) return;
+    const u64 start0 = h->hdr_end + 1;
+    const u64 Draw = h->first_hdr2 - start0;
+    const u64 rmax = std::min<u64>(row_cap, n / (Draw + 3) + 2);
+    if (threadIdx.x == 0) first_bad = rmax;
+    __syncthreads();
+    // row r is linked iff its header sits right behind row r-1's data + newline and has a data start
+    for (u64 r = 1 + threadIdx.x; r < rmax; r += blockDim.x) {
+        const u64 prev = r == 1 ? start0 : cand[r - 1];
+        const bool ok = prev != IDX_NONE && hpos[r] == prev + Draw + 1 && cand[r] != IDX_NONE && cand[r] + Draw <= n;
+        if (!ok) atomicMin(&first_bad, r);
+    }
+    __syncthreads();
+    const u64 S = first_bad;                                   // rows 0 .. S-1 chain; row S must not exist
+    if (S < 2 || S >= rmax) return;                            // (S >= rmax: could not see the end)
+    if (hpos[S] != IDX_NONE) return;                           // something was found there but did not link
+    const u64 q = (S == 1 ? start0 : cand[S - 1]) + Draw;      // behind the last row's data
+    __shared__ u32 tail_bad;
+    if (threadIdx.x == 0) tail_bad = 0;
+    __syncthreads();
+    if (q < n) {                                               // "\n" and then nothing but blank lines (<= 4096 bytes)
+        if (n - q > 4097) { if (threadIdx.x == 0) tail_bad = 1; }
+        else for (u64 i = q + threadIdx.x; i < n; i += blockDim.x) if (f[i] != '\n') tail_bad = 1;
+    }
+    __syncthreads();
+    if (tail_bad) return;
+    for (u64 r = threadIdx.x; r < S; r += blockDim.x) row_start[r] = r ? cand[r] : start0;
+    if (threadIdx.x == 0) { h->idx_bad = S; h->S = S; __threadfence(); h->idx_done = 1; }
+}
+
 __global__ void k_index_rows(const uint8_t* __restrict__ f, u64 n, MsaHdr* h,
                              u64* __restrict__ row_start, u64 row_cap)
 {
@@ -125,7 +219,9 @@ __global__ void k_index_rows(const uint8_t* __restrict__ f, u64 n, MsaHdr* h,
     // row's final newline, the next header's '>' and (headers are short) the header's newline.
     u64 s = 0, bad = 0;
     u64 st = start0;                                   // row 0: its header was found by k_find_hdr_end
-    while (true) {
+    const bool spec = h->idx_done != 0;                // k_index_check validated the parallel index
+    if (spec) s = h->S;
+    while (!spec) {
         if (st + Draw > n) { bad = ST_LAYOUT; break; }
         if (s >= row_cap) { bad = ST_TOO_MANY_ROWS; break; }
         if (lane == 0) row_start[s] = st;
@@ -1958,6 +2054,11 @@ void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t s
     // ---- K0: geometry + row index (one host sync: everything below is sized from it)
     TIMED("k_find_hdr_end", st, hipLaunchKernelGGL(k_find_hdr_end, dim3(1), dim3(64), 0, st, d_msa, (u64)n, dh));
     TIMED("k_find_row0", st, hipLaunchKernelGGL(k_find_row0, dim3(512), dim3(1024), 0, st, d_msa, (u64)n, dh));
+    idx_tmp_.ensure(2 * sizeof(u64) * ROW_CAP);
+    TIMED("k_index_spec", st, hipLaunchKernelGGL(k_index_spec, dim3(512), dim3(256), 0, st, d_msa, (u64)n, dh,
+                                                 idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + ROW_CAP, (u64)ROW_CAP));
+    TIMED("k_index_check", st, hipLaunchKernelGGL(k_index_check, dim3(1), dim3(1024), 0, st, d_msa, (u64)n, dh,
+                                                  idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + ROW_CAP, rows_.as<u64>(), (u64)ROW_CAP));
     TIMED("k_index_rows", st, hipLaunchKernelGGL(k_index_rows, dim3(1), dim3(64), 0, st, d_msa, (u64)n, dh,
                                                  rows_.as<u64>(), (u64)ROW_CAP));
     EDSX_HIP(hipMemcpyAsync(&h_, dh, sizeof(MsaHdr), hipMemcpyDeviceToHost, st));

@@ -42,6 +42,8 @@ struct MsaHdr {
     u64 tmp_total;
     u64 slow_n;        // variant segments left to the generic (workgroup-per-segment) kernels: by shape
     u64 slow_n2;       // ... and those the fast kernel gave up on (more than KCAP distinct strings)
+    u64 idx_done;      // the speculative parallel row index validated: k_index_rows skips its chain
+    u64 idx_bad;       // first row whose speculative header position did not validate
 };
 
 // Row order inside one vc column.  Rows are dealt round-robin over the 64 lanes of a wave in
@@ -120,7 +122,7 @@ private:
     std::vector<TimedKernel> timed_;
 
     DevBuf hdr_, rows_, vraw_, v_, wslot_, vc_, hrun_, hseg_, cnt_, wbase_, segbase_, scan_tmp_,
-           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, grec_, colbuf_;
+           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, grec_, colbuf_, idx_tmp_;
     u64 vc_cap_cols_ = 0;
 
     // emit-time view

@@ -105,3 +105,43 @@ def test_synthetic_slabs_match_whole(ctx):
         ctx.msa_synth_device(part.data_ptr(), m, S, c1 - c0, col0=c0, seed=5)
         prow = [r.split(b"\n")[1] for r in bytes(part.cpu().numpy()).split(b">")[1:]]
         assert prow == [r[c0:c1] for r in rows]
+
+
+def _msa_with_headers(rng, headers, L, lw=None, trailing="\n", inject=None):
+    ref = [rng.choice("ACGT") for _ in range(L)]
+    out = []
+    for i, h in enumerate(headers):
+        row = list(ref)
+        for c in range(0, L, 37):
+            if rng.random() < 0.5:
+                row[c] = rng.choice("ACGT-")
+        if inject and i == inject[0]:
+            row[inject[1]] = inject[2]
+        s = "".join(row)
+        out.append(h)
+        w = lw or L
+        out.extend(s[k:k + w] for k in range(0, L, w))
+    return ("\n".join(out) + trailing).encode()
+
+
+def test_row_index_speculation_and_fallback(ctx):
+    """The row starts come from a speculative parallel search that is validated on the device, with the
+    serial header chain as fallback: equal-length headers (speculation holds), headers whose lengths
+    drift away from the first one (windows miss -> fallback), a '>' inside a data line, blank lines at
+    the end, no final newline.  (A '>' at the START of a wrapped data line is a header line to the
+    reference, i.e. a ragged alignment: rejected input)"""
+    rng = random.Random(5)
+    S, L = 40, 6000
+    cases = [
+        _msa_with_headers(rng, [">seq%03d" % i for i in range(S)], L),
+        _msa_with_headers(rng, [">seq%03d" % i for i in range(S)], L, lw=60),
+        _msa_with_headers(rng, [">s" + "x" * (3 * i) for i in range(S)], L),                 # drifting header lengths
+        _msa_with_headers(rng, [">s%d" % (10 ** (i % 7)) for i in range(S)], L, lw=100),
+        _msa_with_headers(rng, [">seq%03d" % i for i in range(S)], L, lw=60, inject=(7, 121, ">")),      # '>' inside a line
+        _msa_with_headers(rng, [">seq%03d" % i for i in range(S)], L, trailing="\n\n\n"),
+        _msa_with_headers(rng, [">seq%03d" % i for i in range(S)], L, trailing=""),
+        _msa_with_headers(rng, [">r%d" % i for i in range(300)], 9000, lw=70),
+    ]
+    for i, msa in enumerate(cases):
+        for l in (0, 5):
+            assert ctx.msa_transform(msa, l) == o.msa(msa, l), (i, l)
