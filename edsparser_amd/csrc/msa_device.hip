@@ -353,6 +353,14 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 
     const uint8_t* f = p.file;
     const u32 Sm1 = p.S - 1;
+    // rows of this thread.  Plain: sub, sub + RI, ...  Lane rows (S <= 1024, RI == 4 * Gp): the rows
+    // whose bytes are consecutive in a vc column, vc_pos(row_of(it)) == sub * 16 + it:
+    //   row_of(it) = sub * (16 / Gp) + it / Gp + 64 * (it % Gp)      (Gp = 16: sub + 64 * it)
+    const u32 gl = 31u - (u32)__builtin_clz(p.Gp);             // log2(Gp), Gp a power of two
+    auto row_of = [&](u32 it) -> u32 {
+        if constexpr (LANEROWS) return (sub << (4u - gl)) + (it >> gl) + 64u * (it & (p.Gp - 1u));
+        else return sub + it * RI;
+    };
     uint4 ref = make_uint4(0, 0, 0, 0);
     uint4 d[HOLD ? RPT : 1];
     uint4 acc = make_uint4(0, 0, 0, 0);                        // OR over rows of (row ^ ref): a byte is
@@ -360,7 +368,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
         ref = load16u(f + rs[0] + q);                          // fast path: unconditional 16-B loads
 #pragma unroll
         for (int it = 0; it < RPT; it++) {
-            const u32 r = sub + it * RI;
+            const u32 r = row_of(it);
             d[HOLD ? it : 0] = EDSX_K1_LOAD(f + rs[r < p.S ? r : Sm1] + q);   // clamped: rows past S re-read row S-1
             if constexpr (!HOLD) {
                 acc.x |= d[0].x ^ ref.x; acc.y |= d[0].y ^ ref.y; acc.z |= d[0].z ^ ref.z; acc.w |= d[0].w ^ ref.w;
@@ -377,7 +385,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
         if (nb > 0) ref = load_partial(f + rs[0] + q, nb);
 #pragma unroll
         for (int it = 0; it < RPT; it++) {
-            const u32 r = sub + it * RI;
+            const u32 r = row_of(it);
             uint4 v = ref;
             if (r < p.S && nb > 0) v = load_partial(f + rs[r] + q, nb);
             d[HOLD ? it : 0] = v;
@@ -459,7 +467,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                     if (V16 & (1u << I)) {                                                     \
                         if (idx >= b0 && idx < b0 + cap) {                                     \
                             uint8_t* dst = colbuf + (size_t)(idx - b0) * p.Spad;               \
-                            if constexpr (LANEROWS) { /* RI == 64, Gp == 16: this thread's 16 rows are 16 */ \
+                            if constexpr (LANEROWS) { /* RI == 4 * Gp: this thread's 16 rows are 16 */ \
                                 constexpr int TI = LANEROWS ? I : 0; /* consecutive bytes of the permuted column */ \
                                 *reinterpret_cast<uint4*>(dst + sub * 16) = make_uint4(tr[TI][0], tr[TI][1], tr[TI][2], tr[TI][3]); \
                             } else {                                                           \
@@ -1281,7 +1289,8 @@ __device__ __forceinline__ bool fast_group_dna1(const uint4& x, const uint4& vma
 //                state, v_mad_u32_u24 = full rate, fed only by its non-gap letters, + its length),
 //                rows are grouped by that signature.  The cost does not depend on the number of
 //                groups; two different strings of one segment collide with probability ~2^-72.
-template <bool CHECK_NL>
+// NR: rows per lane that can exist (16; 4 when S <= 256)
+template <bool CHECK_NL, int NR>
 __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 meta, const uint4& col0, u32 lane,
                                            const uint4& vmask, FastGroups& G, u32& saw_nl)
 {
@@ -1322,7 +1331,7 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
 #pragma unroll
         for (int i = 0; i < 16; i++) key[i] = 0;
         u32 badacc = 0;
-#define EDSX_K(I) key[I] |= byte_at<I>(cls) << sh;
+#define EDSX_K(I) if constexpr (I < NR) key[I] |= byte_at<I>(cls) << sh;
         for (u32 c0 = 0; c0 < ncol; c0 += 4) {
             uint4 cvs[4];                              // four column loads in flight
 #pragma unroll
@@ -1354,15 +1363,17 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
                 const u32 i0 = first_remaining(rm, leader);
                 u32 mk = 0;
 #pragma unroll
-                for (int i = 0; i < 16; i++) mk = (i0 == (u32)i) ? key[i] : mk;
+                for (int i = 0; i < NR; i++) mk = (i0 == (u32)i) ? key[i] : mk;
                 const u32 rk = (u32)__builtin_amdgcn_readlane((int)mk, leader);
                 uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     if (key[i] == rk) e0 |= 0xffu << (i * 8);
-                    if (key[i + 4] == rk) e1 |= 0xffu << (i * 8);
-                    if (key[i + 8] == rk) e2 |= 0xffu << (i * 8);
-                    if (key[i + 12] == rk) e3 |= 0xffu << (i * 8);
+                    if constexpr (NR > 4) {
+                        if (key[i + 4] == rk) e1 |= 0xffu << (i * 8);
+                        if (key[i + 8] == rk) e2 |= 0xffu << (i * 8);
+                        if (key[i + 12] == rk) e3 |= 0xffu << (i * 8);
+                    }
                 }
                 const uint4 eq = make_uint4(e0 & rm.x, e1 & rm.y, e2 & rm.z, e3 & rm.w);
                 // the group's string: its key without the gap classes (wave-uniform scalar work)
@@ -1476,6 +1487,7 @@ __device__ __forceinline__ uint4 fast_load_col(const MsaView& mv, u64 meta, u32 
 
 // K3 fast: sizes of the variant segments.  Variant and common segments alternate, so the
 // variant ones are seg = 2*vi + p0.
+template <int NR>
 __global__ void __launch_bounds__(256, 4) k_seg_count_fast(FastParams p)
 {
     const MsaView& mv = p.mv;
@@ -1501,7 +1513,7 @@ __global__ void __launch_bounds__(256, 4) k_seg_count_fast(FastParams p)
 
         bool fast = (meta & META_FAST) != 0;
         FastGroups G;
-        if (fast) fast = fast_group<true>(mv, (meta & META_SCATTER) ? uniform64(p.seg_start[seg]) : 0, meta, col, lane, vmask, G, saw_nl);
+        if (fast) fast = fast_group<true, NR>(mv, (meta & META_SCATTER) ? uniform64(p.seg_start[seg]) : 0, meta, col, lane, vmask, G, saw_nl);
         uint8_t* rec = p.grec + vi * (u64)GREC_BYTES;
         // wait for the prefetched column here, before this segment's stores are queued behind it
         // (vmcnt retires in issue order: see k_emit_variant_fast)
@@ -1705,6 +1717,8 @@ __device__ __forceinline__ u32 wave_scan_incl(u32 v)
 
 // Up to four groups (ids 0..3 in `gid`; rows with weight 0 in `wv` are not placed).  Group g's list
 // starts at text + run0 + (lists before it); returns the offset behind the last list.
+// NB: blocks of 64 rows that can hold rows (16; 4 when S <= 256, where only gid.x / wv.x are looked at).
+template <int NB>
 __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8_t* text, const u32 (&tokc)[16],
                                                   const uint4& wv, u32 lane, u32 run0)
 {
@@ -1715,7 +1729,7 @@ __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8
     // byte totals, 16-bit fields: A[0] = groups 0 (low half) and 2, A[1] = groups 1 and 3
     u32 A[2] = {0, 0};
 #define EDSX_A(I)                                                                                 \
-    {                                                                                             \
+    if constexpr (I < NB) {                                                                       \
         const u32 gi = byte_at<I>(gid);                                                           \
         const u32 f = byte_at<I>(wv) << ((gi << 3) & 31u);                                        \
         const u32 inc = wave_scan_incl(f);                                                        \
@@ -1729,7 +1743,8 @@ __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8
     EDSX_A(0) EDSX_A(1) EDSX_A(2) EDSX_A(3) EDSX_A(4) EDSX_A(5) EDSX_A(6) EDSX_A(7)
     EDSX_A(8) EDSX_A(9) EDSX_A(10) EDSX_A(11) EDSX_A(12) EDSX_A(13) EDSX_A(14)
 #undef EDSX_A
-    {
+    ex15[0] = ex15[1] = tot15[0] = tot15[1] = 0;
+    if constexpr (NB == 16) {
         const u32 gi = byte_at<15>(gid);
         const u32 f = byte_at<15>(wv) << (((gi >> 1) & 1u) * 16u);
 #pragma unroll
@@ -1756,7 +1771,7 @@ __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8
     }
 #define EDSX_CUR(gi) ((((gi & 1u) ? C[1] : C[0]) >> (((gi >> 1) & 1u) * 16u)) & 0xffffu)
 #define EDSX_B(I)                                                                                 \
-    {                                                                                             \
+    if constexpr (I < NB) {                                                                       \
         const u32 gi = byte_at<I>(gid);                                                           \
         const u32 rank = (ex[I] >> ((gi << 3) & 31u)) & 0xffu;                                    \
         const u32 off = EDSX_CUR(gi) + ((I >= 2) ? rank << 2 : rank);                             \
@@ -1773,7 +1788,7 @@ __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8
     EDSX_B(0) EDSX_B(1) EDSX_B(2) EDSX_B(3) EDSX_B(4) EDSX_B(5) EDSX_B(6) EDSX_B(7)
     EDSX_B(8) EDSX_B(9) EDSX_B(10) EDSX_B(11) EDSX_B(12) EDSX_B(13) EDSX_B(14)
 #undef EDSX_B
-    {
+    if constexpr (NB == 16) {
         const u32 gi = byte_at<15>(gid);
         const u32 pk = (gi & 1u) ? ex15[1] : ex15[0];
         const u32 off = EDSX_CUR(gi) + ((pk >> (((gi >> 1) & 1u) * 16u)) & 0xffffu);
@@ -1793,6 +1808,7 @@ __device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8
 
 // More than four groups (k <= 16): four at a time.  The group ids outside the current quartet get
 // weight 0 (SWAR: a byte is inside iff (id ^ base) & 0xFC == 0), the ids inside become 0..3.
+template <int NB>
 __device__ __forceinline__ u32 fast_emit_ids_cols_multi(const uint4& gid, u32 k, uint8_t* text, const u32 (&tokc)[16],
                                                         const uint4& wv, u32 lane)
 {
@@ -1804,11 +1820,12 @@ __device__ __forceinline__ u32 fast_emit_ids_cols_multi(const uint4& gid, u32 k,
         { const u32 x = gid.C ^ bb; g2.C = x & 0x03030303u; w2.C = wv.C & ~bytes_ne_mask(x & 0xfcfcfcfcu, 0u); }
         EDSX_Q(x) EDSX_Q(y) EDSX_Q(z) EDSX_Q(w)
 #undef EDSX_Q
-        run = fast_emit_ids_cols(g2, k - gb < 4u ? k - gb : 4u, text, tokc, w2, lane, run);
+        run = fast_emit_ids_cols<NB>(g2, k - gb < 4u ? k - gb : 4u, text, tokc, w2, lane, run);
     }
     return run;
 }
 
+template <int NB>
 __global__ void __launch_bounds__(256, 4) k_emit_variant_fast(FastParams p)
 {
     __shared__ __attribute__((aligned(16))) u64 tok_sh[1024];
@@ -1883,8 +1900,8 @@ __global__ void __launch_bounds__(256, 4) k_emit_variant_fast(FastParams p)
         const u32 sh = (u32)goff & 15u;
         if (fast) {
             uint8_t* text = stage + sh;                    // LDS offset == global offset (mod 16)
-            if (G.k <= 4) n = fast_emit_ids_cols(G.gid, G.k, text, tokc, wgt, lane, 0u);
-            else if (G.k <= 16) n = fast_emit_ids_cols_multi(G.gid, G.k, text, tokc, wgt, lane);
+            if (G.k <= 4) n = fast_emit_ids_cols<NB>(G.gid, G.k, text, tokc, wgt, lane, 0u);
+            else if (G.k <= 16) n = fast_emit_ids_cols_multi<NB>(G.gid, G.k, text, tokc, wgt, lane);
             else n = fast_emit_ids<0>(G.gid, G.k, text, tok_sh, lane);
         }
         // the wait for the prefetched record (and with it for the previous segment's stores) goes here
@@ -2146,7 +2163,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     kp.cpr_log2 = cpr_log2; kp.cap_cols = (u32)(colbuf_bytes / Spad); kp.ntiles = ntiles;
     if (kp.cap_cols == 0) throw FormatError(status_message(ST_TOO_MANY_ROWS));
     launch_timer_begin("k_scan_extract", st);
-    const bool lane_rows = hold && RPT == 16 && (T >> cpr_log2) == 64 && kp.Gp == 16;   // thread rows = one lane's 16 bytes
+    const bool lane_rows = hold && RPT == 16 && S <= 1024 && (u32)(T >> cpr_log2) == 4 * kp.Gp;   // thread rows = 16 consecutive vc bytes
     if (cfg == 1) {
         if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
         else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
@@ -2233,8 +2250,13 @@ void MsaPipeline::plan_body(hipStream_t st)
         fp_.grec = grec_.as<uint8_t>();
         EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, 2 * sizeof(u64), st));
         TIMED("k_seg_meta", st, hipLaunchKernelGGL(k_seg_meta, dim3(4096), dim3(256), 0, st, fp_));
-        TIMED("k_seg_count_fast", st, hipLaunchKernelGGL(k_seg_count_fast, dim3(persistent_grid(
-                  reinterpret_cast<const void*>(k_seg_count_fast), 256, 0)), dim3(256), 0, st, fp_));
+        if (S <= 256) {                                       // at most four rows per lane: leaner instantiation
+            TIMED("k_seg_count_fast", st, hipLaunchKernelGGL(k_seg_count_fast<4>, dim3(persistent_grid(
+                      reinterpret_cast<const void*>(k_seg_count_fast<4>), 256, 0)), dim3(256), 0, st, fp_));
+        } else {
+            TIMED("k_seg_count_fast", st, hipLaunchKernelGGL(k_seg_count_fast<16>, dim3(persistent_grid(
+                      reinterpret_cast<const void*>(k_seg_count_fast<16>), 256, 0)), dim3(256), 0, st, fp_));
+        }
         sp.list = fp_.slow_list; sp.list_n = fp_.slow_count;
         TIMED("k_seg_count_slow", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
         sp.list = fp_.slow_list2; sp.list_n = fp_.slow_count2;
@@ -2333,8 +2355,13 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
         TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
         FastParams fp = fp_;
         fp.eds = d_eds; fp.seds = d_seds;
-        TIMED("k_emit_variant_fast", st, hipLaunchKernelGGL(k_emit_variant_fast, dim3(persistent_grid(
-                  reinterpret_cast<const void*>(k_emit_variant_fast), 256, 0)), dim3(256), 0, st, fp));
+        if (h_.S <= 256) {                                    // at most four blocks of 64 rows
+            TIMED("k_emit_variant_fast", st, hipLaunchKernelGGL(k_emit_variant_fast<4>, dim3(persistent_grid(
+                      reinterpret_cast<const void*>(k_emit_variant_fast<4>), 256, 0)), dim3(256), 0, st, fp));
+        } else {
+            TIMED("k_emit_variant_fast", st, hipLaunchKernelGGL(k_emit_variant_fast<16>, dim3(persistent_grid(
+                      reinterpret_cast<const void*>(k_emit_variant_fast<16>), 256, 0)), dim3(256), 0, st, fp));
+        }
         ep.list = fp_.slow_list; ep.list_n = fp_.slow_count;
         TIMED("k_emit_variant_slow", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
         ep.list = fp_.slow_list2; ep.list_n = fp_.slow_count2;

@@ -51,7 +51,15 @@ struct MsaHdr {
 // at lane*Gp hands lane `lane` the rows lane, lane+64, lane+128, ...  (Gp = rows per lane = 16,
 // or ceil(S/64) when S <= 1024).  Consecutive row ids then sit in consecutive lanes, which makes
 // the id lists of the .seds a dense lane-parallel write.
-__host__ __device__ inline u32 vc_rows_per_lane(u32 S) { return S > 1024 ? 16u : (S + 63u) / 64u; }
+// rows per lane: a power of two (1, 2, 4, 8, 16), so that the 16 rows a K1 thread holds are 16
+// CONSECUTIVE bytes of a vc column for every S <= 1024 (see k_scan_extract, "lane rows")
+__host__ __device__ inline u32 vc_rows_per_lane(u32 S)
+{
+    if (S > 512) return 16u;
+    u32 g = 1;
+    while (64u * g < S) g <<= 1;
+    return g;
+}
 __host__ __device__ inline u32 vc_pitch(u32 S)
 {
     const u32 gp = vc_rows_per_lane(S);
