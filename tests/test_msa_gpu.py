@@ -145,3 +145,27 @@ def test_row_index_speculation_and_fallback(ctx):
     for i, msa in enumerate(cases):
         for l in (0, 5):
             assert ctx.msa_transform(msa, l) == o.msa(msa, l), (i, l)
+
+
+def test_baseline_config_64x10mb_bit_exact(ctx):
+    """BASELINE.json configs[1] at full size: 64 sequences x 10 Mb (640 MB), device-resident path,
+    every output byte against the oracle (about 3 s of CPU work), plus l-EDS with l = 10."""
+    import hashlib
+    import torch
+    import edsparser_amd
+    S, L = 64, 10_000_000
+    n = edsparser_amd.synth_size(S, L)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_synth_device(buf.data_ptr(), n, S, L, variant_fraction=0.05, seed=42)
+    torch.cuda.synchronize()
+    host = bytes(buf.cpu().numpy())
+    for l in (0, 10):
+        E, Q = ctx.msa_plan_device(buf.data_ptr(), n, l)
+        d_eds = torch.empty(E + 16, dtype=torch.uint8, device="cuda:0")
+        d_seds = torch.empty(Q + 16, dtype=torch.uint8, device="cuda:0")
+        ctx.msa_emit_device(d_eds.data_ptr(), d_seds.data_ptr())
+        torch.cuda.synchronize()
+        oe, os_ = o.msa(host, l)
+        assert (E, Q) == (len(oe), len(os_)), l
+        assert hashlib.sha256(d_eds[:E].cpu().numpy().tobytes()).digest() == hashlib.sha256(oe).digest(), l
+        assert hashlib.sha256(d_seds[:Q].cpu().numpy().tobytes()).digest() == hashlib.sha256(os_).digest(), l

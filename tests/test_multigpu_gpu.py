@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, S, Lr, seed, q):
+def _worker(rank, world, port, S, Lr, seed, q, vfrac=0.3):
     import torch
     import torch.distributed as dist
     import edsparser_amd
@@ -32,7 +32,7 @@ def _worker(rank, world, port, S, Lr, seed, q):
         mini = edsparser_amd.Context(0)
         n = edsparser_amd.synth_size(S, Lr)
         buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
-        ctx.msa_synth_device(buf.data_ptr(), n, S, Lr, col0=rank * Lr, variant_fraction=0.3, seed=seed)
+        ctx.msa_synth_device(buf.data_ptr(), n, S, Lr, col0=rank * Lr, variant_fraction=vfrac, seed=seed)
         E, Q = ctx.msa_plan_device(buf.data_ptr(), n, 0)
         d_e = torch.empty(E + 16, dtype=torch.uint8, device="cuda:0")
         d_s = torch.empty(Q + 16, dtype=torch.uint8, device="cuda:0")
@@ -72,3 +72,37 @@ def test_two_slabs_on_one_gpu(S, Lr, seed):
     torch.cuda.synchronize()
     want = ctx.msa_transform(bytes(buf.cpu().numpy()), 0)
     assert (eds, seds) == want
+
+
+def test_bench_shape_slabs_vs_whole():
+    """The bench workload's shape at 1/10 of its width (1000 rows x 10 M columns, 5 % sites, 10 GB): two
+    column slabs transformed by two ranks and stitched must give, byte for byte, the single-GPU
+    transform of the whole alignment (1.7 GB of .seds).  A size-independent property: it exercises
+    every kernel of the fast path at the bench's row count and the boundary stitch, without the oracle."""
+    import hashlib
+    import torch
+    import torch.multiprocessing as mp
+    import edsparser_amd
+    S, Lr, seed = 1000, 5_000_000, 42
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, S, Lr, seed, q, 0.05)) for r in range(2)]
+    for p in procs:
+        p.start()
+    eds, seds, chains = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    ctx = edsparser_amd.Context(0)
+    n = edsparser_amd.synth_size(S, 2 * Lr)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_synth_device(buf.data_ptr(), n, S, 2 * Lr, col0=0, variant_fraction=0.05, seed=seed)
+    E, Q = ctx.msa_plan_device(buf.data_ptr(), n, 0)
+    d_e = torch.empty(E + 16, dtype=torch.uint8, device="cuda:0")
+    d_s = torch.empty(Q + 16, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_emit_device(d_e.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    assert (len(eds), len(seds)) == (E, Q)
+    assert hashlib.sha256(eds).digest() == hashlib.sha256(d_e[:E].cpu().numpy().tobytes()).digest()
+    assert hashlib.sha256(seds).digest() == hashlib.sha256(d_s[:Q].cpu().numpy().tobytes()).digest()
