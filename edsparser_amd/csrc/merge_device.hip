@@ -18,6 +18,7 @@
 //   symbols           size[i], ent_off[i], len1[i] (length of the only string when size == 1)
 //                     for the current round, double buffered.
 #include "merge_device.hpp"
+#include <thread>
 
 #include <algorithm>
 #include <cctype>
@@ -270,6 +271,128 @@ std::string normalize(const std::string& in)                 // eds.cpp:831-881
     return out;
 }
 
+// ---- chunk-parallel host tokenisers ---------------------------------------------------------------
+// .eds / .seds text is a sequence of brace groups that do not nest, so a cut right behind any '}' is a
+// point where the sequential tokenisers below are in their initial state.  Large inputs are cut there and
+// tokenised by several host threads into flat arrays.  The fast path only accepts well-formed text;
+// anything else (nesting, a stray brace, a character that does not belong, an empty source set, a number
+// beyond int) makes it give up, and the sequential code then produces the reference's error text.
+unsigned tokenizer_threads(size_t n)
+{
+    static long par_min = -1;
+    if (par_min < 0) { const char* e = getenv("EDSX_TOKENIZE_PAR_MIN"); par_min = e ? atol(e) : (1l << 20); }
+    if ((long)n < par_min) return 1;
+    const unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(16u, hc ? hc : 4u));
+}
+std::vector<size_t> brace_cuts(const uint8_t* p, size_t n, unsigned nt)
+{
+    std::vector<size_t> cut(nt + 1, n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < nt; t++) {
+        size_t g = (size_t)((unsigned __int128)n * t / nt);
+        if (g < cut[t - 1]) g = cut[t - 1];
+        const uint8_t* b = g < n ? static_cast<const uint8_t*>(memchr(p + g, '}', n - g)) : nullptr;
+        cut[t] = b ? static_cast<size_t>(b - p) + 1 : n;
+    }
+    return cut;
+}
+struct EdsPart { std::vector<uint8_t> chars; std::vector<u64> str_end; std::vector<u64> sym_nstr; bool ok = true; };
+void tokenize_eds_range(const uint8_t* p, size_t lo, size_t hi, EdsPart& out)
+{
+    out.chars.reserve(hi - lo);
+    int depth = 0;
+    bool run_open = false;                                   // a bare run (text outside braces) is being collected
+    u64 nstr = 0;
+    auto close_symbol = [&] { out.str_end.push_back(out.chars.size()); out.sym_nstr.push_back(nstr + 1); nstr = 0; };
+    for (size_t i = lo; i < hi; i++) {
+        const uint8_t ch = p[i];
+        if (std::isspace(ch)) continue;
+        if (ch == '{') {
+            if (depth) { out.ok = false; return; }           // nesting
+            if (run_open) { close_symbol(); run_open = false; }
+            depth = 1;
+        } else if (ch == '}') {
+            if (!depth) { out.ok = false; return; }          // stray brace
+            close_symbol();
+            depth = 0;
+        } else if (ch == ',') { out.str_end.push_back(out.chars.size()); nstr++; if (!depth) run_open = true; }
+        else { out.chars.push_back(ch); if (!depth) run_open = true; }
+    }
+    if (depth) { out.ok = false; return; }                   // unterminated group
+    if (run_open) close_symbol();
+}
+// fills chars / str_off / sym_first like the sequential tokeniser; false: not well-formed, use that one
+bool tokenize_eds_parallel(const uint8_t* p, size_t n, std::vector<uint8_t>& chars, std::vector<u64>& str_off,
+                           std::vector<u64>& sym_first)
+{
+    const unsigned nt = tokenizer_threads(n);
+    if (nt < 2) return false;
+    const std::vector<size_t> cut = brace_cuts(p, n, nt);
+    std::vector<EdsPart> parts(nt);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { tokenize_eds_range(p, cut[t], cut[t + 1], parts[t]); });
+    for (auto& x : th) x.join();
+    size_t nc = 0, ns = 0, ny = 0;
+    for (const auto& pt : parts) { if (!pt.ok) return false; nc += pt.chars.size(); ns += pt.str_end.size(); ny += pt.sym_nstr.size(); }
+    chars.resize(nc); str_off.assign(ns + 1, 0); sym_first.assign(ny + 1, 0);
+    std::vector<size_t> c0(nt + 1, 0), s0(nt + 1, 0), y0(nt + 1, 0);
+    for (unsigned t = 0; t < nt; t++) {
+        c0[t + 1] = c0[t] + parts[t].chars.size(); s0[t + 1] = s0[t] + parts[t].str_end.size(); y0[t + 1] = y0[t] + parts[t].sym_nstr.size();
+    }
+    th.clear();
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            const EdsPart& pt = parts[t];
+            if (!pt.chars.empty()) memcpy(chars.data() + c0[t], pt.chars.data(), pt.chars.size());
+            for (size_t i = 0; i < pt.str_end.size(); i++) str_off[s0[t] + i + 1] = c0[t] + pt.str_end[i];
+            u64 first = s0[t];
+            for (size_t i = 0; i < pt.sym_nstr.size(); i++) { first += pt.sym_nstr[i]; sym_first[y0[t] + i + 1] = first; }
+        });
+    for (auto& x : th) x.join();
+    return true;
+}
+struct SedsPart { std::vector<int> ids; std::vector<u64> set_end; int maxid = 0; bool ok = true; };
+void tokenize_seds_range(const uint8_t* p, size_t lo, size_t hi, SedsPart& out)
+{
+    int depth = 0;
+    bool have = false;
+    long long val = 0;
+    size_t set_begin = 0;
+    auto flush = [&] { if (have) { out.ids.push_back((int)val); out.maxid = std::max(out.maxid, (int)val); } have = false; val = 0; };
+    for (size_t i = lo; i < hi; i++) {
+        const uint8_t ch = p[i];
+        if (std::isspace(ch)) continue;
+        if (!depth) {
+            if (ch != '{') { out.ok = false; return; }
+            depth = 1; set_begin = out.ids.size();
+        } else if (ch == '}') {
+            flush();
+            if (out.ids.size() == set_begin) { out.ok = false; return; }      // empty path set
+            out.set_end.push_back(out.ids.size());
+            depth = 0;
+        } else if (ch == ',') flush();
+        else if (ch >= '0' && ch <= '9') {
+            val = val * 10 + (ch - '0'); have = true;
+            if (val > 2147483647ll) { out.ok = false; return; }               // std::stoi would throw
+        } else { out.ok = false; return; }
+    }
+    if (depth) out.ok = false;
+}
+bool tokenize_seds_parallel(const uint8_t* p, size_t n, std::vector<SedsPart>& parts, u64& nsets, int& maxid)
+{
+    const unsigned nt = tokenizer_threads(n);
+    if (nt < 2) return false;
+    const std::vector<size_t> cut = brace_cuts(p, n, nt);
+    parts.assign(nt, SedsPart());
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { tokenize_seds_range(p, cut[t], cut[t + 1], parts[t]); });
+    for (auto& x : th) x.join();
+    nsets = 0; maxid = 0;
+    for (const auto& pt : parts) { if (!pt.ok) return false; nsets += pt.set_end.size(); maxid = std::max(maxid, pt.maxid); }
+    return nsets > 0;
+}
+
 void grow_keep(DevBuf& b, size_t used, size_t need, hipStream_t st)
 {
     if (need <= b.cap) return;
@@ -292,7 +415,8 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     // ---- host tokeniser: eds.cpp:39-155 (same error texts)
     std::vector<uint8_t> chars;
     std::vector<u64> str_off{0}, sym_first{0};
-    {
+    if (!tokenize_eds_parallel(eds, eds_n, chars, str_off, sym_first)) {
+        chars.clear(); str_off.assign(1, 0); sym_first.assign(1, 0);
         std::string in = strip_ws(eds, eds_n);
         if (!in.empty()) {
             in = normalize(in);
@@ -318,7 +442,25 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     // ---- sources: eds.cpp:268-355 -> bitsets
     u32 W = 1;
     std::vector<u64> bits;
-    if (linear) {
+    std::vector<SedsPart> sparts;
+    u64 par_sets = 0;
+    int par_maxid = 0;
+    if (linear && tokenize_seds_parallel(seds, seds_n, sparts, par_sets, par_maxid) && par_sets == m) {
+        W = (u32)(par_maxid / 64 + 1);
+        bits.assign((size_t)m * W, 0);
+        std::vector<size_t> base(sparts.size() + 1, 0);
+        for (size_t t = 0; t < sparts.size(); t++) base[t + 1] = base[t] + sparts[t].set_end.size();
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < sparts.size(); t++)
+            th.emplace_back([&, t] {
+                const SedsPart& pt = sparts[t];
+                size_t b = 0;
+                for (size_t sidx = 0; sidx < pt.set_end.size(); sidx++) {
+                    for (; b < pt.set_end[sidx]; b++) { const int id = pt.ids[b]; bits[(base[t] + sidx) * W + id / 64] |= 1ull << (id % 64); }
+                }
+            });
+        for (auto& x : th) x.join();
+    } else if (linear) {
         std::string in = strip_ws(seds, seds_n);
         if (in.empty()) throw FormatError("sEDS input is empty");
         std::vector<std::vector<int>> sets;

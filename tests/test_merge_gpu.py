@@ -97,3 +97,56 @@ def test_random_larger_inputs_vs_oracle(ctx, with_src):
             got = _run(ctx, eds, seds, l, compact)
             got.pop("code", None)
             assert got == want, (it, n, l, compact)
+
+
+def _big_eds(rng, nsym, paths, compact_in, spacing):
+    """genrandomeds-like text of >= 1 MB: long common blocks, sites `spacing` symbols apart on average.
+    compact_in: non-degenerate symbols without braces (EDS::save COMPACT), plus whitespace noise."""
+    eds, seds = [], []
+    for i in range(nsym):
+        if i % 2 == 0:
+            s = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, spacing)))
+            eds.append(s if compact_in else "{" + s + "}")
+            seds.append("{0}")
+        else:
+            k = rng.randint(2, 4)
+            alts = ["".join(rng.choice("ACGT") for _ in range(rng.randint(0, 3))) for _ in range(k)]
+            choice = [p if p < k else rng.randrange(k) for p in range(paths)]
+            eds.append("{" + ",".join(alts) + "}")
+            for a in range(k):
+                seds.append("{" + ",".join(str(p + 1) for p in range(paths) if choice[p] == a) + "}")
+        if compact_in and i % 97 == 0:
+            eds.append("\n" if i % 2 else " \t")
+            seds.append("\n")
+    return "".join(eds).encode(), "".join(seds).encode()
+
+
+@pytest.mark.parametrize("compact_in", [False, True])
+def test_parallel_tokenisers_large_inputs(ctx, compact_in):
+    """Inputs of 1 MB and more are cut behind '}' and tokenised by several host threads; the result
+    must be what the sequential tokeniser gives (oracle), for FULL and COMPACT input text, LINEAR and
+    CARTESIAN; a malformed large input must still produce the reference's error text."""
+    rng = random.Random(7 + compact_in)
+    eds, seds = _big_eds(rng, 140000, 6, compact_in, 60)
+    assert len(eds) >= 1 << 20 and len(seds) >= 1 << 20
+    for sd, l in ((seds, 24), (None, 2)):
+        want = o.merge(eds, sd, l, True)
+        got = _run(ctx, eds, sd, l, True)
+        assert got.get("out") == want[0].decode() and got.get("seds_out") == want[1].decode(), (compact_in, l)
+    bad = eds[:700000] + b"{A{C}" + eds[700000:]
+    for sd in (seds, None):
+        try:
+            want = o.merge(bad, sd, 5, True)
+            want = {"out": want[0].decode(), "seds_out": want[1].decode()}
+        except o.OracleError as ex:
+            want = {"error": str(ex)}
+        got = _run(ctx, bad, sd, 5, True)
+        got.pop("code", None)
+        assert got == want
+    bad_s = seds[:100000] + b"{x}" + seds[100000:]
+    try:
+        o.merge(eds, bad_s, 5, True)
+        raise AssertionError("oracle accepted a malformed sEDS")
+    except o.OracleError as ex:
+        got = _run(ctx, eds, bad_s, 5, True)
+        assert got.get("error") == str(ex)
