@@ -363,75 +363,109 @@ bool next_line(const uint8_t* f, size_t n, size_t& pos, std::string& line, bool*
     return true;
 }
 
-struct HostVariant {
-    u64 pos = 0; std::string ref; std::vector<std::string> alts; std::vector<std::vector<int>> gts;
-};
-
 enum class Skip { NONE, HEADER, MALFORMED, UNSUPPORTED_SV };
 
-// parse_alt_field :142-176 — returns false for an unsupported symbolic allele
-bool parse_alts(const std::string& field, const std::string& ref, std::vector<std::string>& alts, std::string& sv)
-{
-    std::stringstream ss(field);
-    std::string a;
-    while (std::getline(ss, a, ',')) {
-        if (!a.empty() && a[0] == '<' && a[a.size() - 1] == '>') {
-            std::string t = a.substr(1, a.size() - 2);
-            if (t == "DEL") alts.push_back("");
-            else if (t == "INS") alts.push_back(ref);
-            else { sv = t; return false; }
-        } else alts.push_back(a);
-    }
-    return true;
-}
-
-std::vector<int> parse_gt(const std::string& gt)             // :190-216
-{
-    std::vector<int> out;
-    const char delim = gt.find('/') != std::string::npos ? '/' : '|';
-    std::stringstream ss(gt);
-    std::string a;
-    while (std::getline(ss, a, delim)) {
-        if (a == ".") continue;
-        try { out.push_back(std::stoi(a)); } catch (...) { continue; }
-    }
-    return out;
-}
-
-bool parse_line(const std::string& line, Skip& skip, HostVariant& var, std::string& warn)   // :232-326
-{
-    skip = Skip::NONE;
-    if (line.empty() || line[0] == '#') { skip = Skip::HEADER; return false; }
-    std::vector<std::string> fields;
+// Records of one stretch of the file, flat (no allocation per record): record i has alts
+// [alt0[i], alt0[i+1]) with characters altoff[..] .. altoff[..+1], and samples [gt0[i], gt0[i+1]) with
+// alleles gtoff[..] .. gtoff[..+1].
+struct VcfPart {
+    std::vector<u64> pos, reflen;
+    std::vector<u64> alt0{0}, altoff{0};
+    std::vector<uint8_t> altchars;
+    std::vector<u64> gt0{0}, gtoff{0};
+    std::vector<int> alleles;
+    VcfCounters st;
+    std::vector<std::string> warns;
+    size_t size() const { return pos.size(); }
+    void drop_open_record()                                  // undo a record that turned out unsupported
     {
-        std::stringstream ss(line);
-        std::string tok;
-        while (std::getline(ss, tok, '\t')) if (!tok.empty()) fields.push_back(tok);
-        if (fields.size() < 5) {
-            fields.clear();
-            std::stringstream ws(line);
-            while (ws >> tok) fields.push_back(tok);
+        altoff.resize(alt0.back() + 1); altchars.resize(altoff.back());
+        gtoff.resize(gt0.back() + 1); alleles.resize(gtoff.back());
+    }
+};
+
+struct Span { const char* p; size_t n; };
+
+// parse_genotype :190-216 — tokens between delimiters as std::getline yields them (a trailing empty one
+// is not produced), "." skipped, std::stoi decides what a number is (exceptions -> token ignored)
+void parse_gt_flat(Span gt, VcfPart& out)
+{
+    const char delim = memchr(gt.p, '/', gt.n) ? '/' : '|';
+    size_t i = 0;
+    while (i < gt.n) {
+        const char* e = static_cast<const char*>(memchr(gt.p + i, delim, gt.n - i));
+        const size_t end = e ? static_cast<size_t>(e - gt.p) : gt.n;
+        const size_t len = end - i;
+        if (!(len == 1 && gt.p[i] == '.')) {
+            if (len == 1 && gt.p[i] >= '0' && gt.p[i] <= '9') out.alleles.push_back(gt.p[i] - '0');
+            else {
+                try { out.alleles.push_back(std::stoi(std::string(gt.p + i, len))); } catch (...) {}
+            }
+        }
+        i = end + 1;
+    }
+}
+
+// parse_vcf_line :232-326 into the flat store; `fields` is scratch
+Skip parse_line_flat(const char* line, size_t n, VcfPart& out, std::vector<Span>& fields)
+{
+    if (n == 0 || line[0] == '#') return Skip::HEADER;
+    fields.clear();
+    for (size_t i = 0; i < n;) {                             // std::getline(ss, tok, '\t'), empty tokens dropped
+        const char* e = static_cast<const char*>(memchr(line + i, '\t', n - i));
+        const size_t end = e ? static_cast<size_t>(e - line) : n;
+        if (end > i) fields.push_back(Span{line + i, end - i});
+        i = end + 1;
+    }
+    if (fields.size() < 5) {                                 // ws >> tok
+        fields.clear();
+        size_t i = 0;
+        while (i < n) {
+            while (i < n && std::isspace((unsigned char)line[i])) i++;
+            size_t j = i;
+            while (j < n && !std::isspace((unsigned char)line[j])) j++;
+            if (j > i) fields.push_back(Span{line + i, j - i});
+            i = j;
         }
     }
-    if (fields.size() < 5) { skip = Skip::MALFORMED; return false; }
-    var = HostVariant();
-    try { var.pos = std::stoull(fields[1]); } catch (...) { skip = Skip::MALFORMED; return false; }
-    var.ref = fields[3];
-    std::string sv;
-    if (!parse_alts(fields[4], var.ref, var.alts, sv)) {
-        warn = "Warning: Skipping variant at " + fields[0] + ":" + std::to_string(var.pos) +
-               " - Unsupported structural variant type: " + sv;
-        skip = Skip::UNSUPPORTED_SV;
-        return false;
+    if (fields.size() < 5) return Skip::MALFORMED;
+    u64 pos;
+    try { pos = std::stoull(std::string(fields[1].p, fields[1].n)); } catch (...) { return Skip::MALFORMED; }
+    const Span ref = fields[3];
+    // parse_alt_field :142-176 — std::getline(ss, a, ','): empty tokens kept, except one behind the last comma
+    const Span alt = fields[4];
+    for (size_t i = 0; i < alt.n;) {
+        const char* e = static_cast<const char*>(memchr(alt.p + i, ',', alt.n - i));
+        const size_t end = e ? static_cast<size_t>(e - alt.p) : alt.n;
+        const char* a = alt.p + i;
+        const size_t len = end - i;
+        if (len && a[0] == '<' && a[len - 1] == '>') {
+            const size_t tl = len >= 2 ? len - 2 : 0;        // "<" alone: substr(1, npos-ish) is empty in the reference too
+            const std::string t = len >= 2 ? std::string(a + 1, tl) : std::string();
+            if (t == "DEL") { out.altoff.push_back(out.altchars.size()); }
+            else if (t == "INS") { out.altchars.insert(out.altchars.end(), ref.p, ref.p + ref.n); out.altoff.push_back(out.altchars.size()); }
+            else {
+                out.drop_open_record();
+                out.warns.push_back("Warning: Skipping variant at " + std::string(fields[0].p, fields[0].n) + ":" +
+                                    std::to_string(pos) + " - Unsupported structural variant type: " + t);
+                return Skip::UNSUPPORTED_SV;
+            }
+        } else { out.altchars.insert(out.altchars.end(), a, a + len); out.altoff.push_back(out.altchars.size()); }
+        i = end + 1;
     }
     if (fields.size() >= 10)
-        for (size_t i = 9; i < fields.size(); i++) {
-            std::string gt = fields[i];
-            size_t c = gt.find(':');
-            if (c != std::string::npos) gt = gt.substr(0, c);
-            var.gts.push_back(parse_gt(gt));
+        for (size_t f = 9; f < fields.size(); f++) {
+            Span gt = fields[f];
+            const char* c = static_cast<const char*>(memchr(gt.p, ':', gt.n));
+            if (c) gt.n = static_cast<size_t>(c - gt.p);
+            parse_gt_flat(gt, out);
+            out.gtoff.push_back(out.alleles.size());
         }
-    return true;
+    out.pos.push_back(pos);
+    out.reflen.push_back(ref.n);
+    out.alt0.push_back(out.altoff.size() - 1);
+    out.gt0.push_back(out.gtoff.size() - 1);
+    return Skip::NONE;
 }
 
 template <class T> void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st)
@@ -467,23 +501,21 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     // ---- VCF records (:690-712) and the unstable sort (:715-718).  Lines are independent: large files
     // are cut at line starts and tokenised by several host threads; records, counters and the stderr
     // warnings are put together in file order, so the array handed to std::sort is the reference's.
-    std::vector<HostVariant> vars;
+    std::vector<VcfPart> parts;
+    std::vector<u64> part_base;                              // first global record index of every part
+    std::vector<std::pair<u64, u32>> order;                  // (pos, global index in file order), sorted by pos
     {
-        struct Part { std::vector<HostVariant> vars; VcfCounters st; std::vector<std::string> warns; };
-        auto parse_range = [&](size_t lo, size_t hi, Part& out) {
+        auto parse_range = [&](size_t lo, size_t hi, VcfPart& out) {
+            std::vector<Span> fields;
             size_t pos = lo;
-            std::string line, warn;
-            while (pos < hi && next_line(vcf, vcf_n, pos, line)) {
-                Skip skip;
-                HostVariant v;
-                const bool ok = parse_line(line, skip, v, warn);
+            while (pos < hi && pos < vcf_n) {
+                const uint8_t* nl = static_cast<const uint8_t*>(memchr(vcf + pos, '\n', vcf_n - pos));
+                const size_t end = nl ? static_cast<size_t>(nl - vcf) : vcf_n;
+                const Skip skip = parse_line_flat(reinterpret_cast<const char*>(vcf + pos), end - pos, out, fields);
                 if (skip == Skip::NONE) { out.st.total_variants++; out.st.processed_variants++; }
                 else if (skip == Skip::MALFORMED) { out.st.total_variants++; out.st.skipped_malformed++; }
-                else if (skip == Skip::UNSUPPORTED_SV) {
-                    out.st.total_variants++; out.st.skipped_unsupported_sv++;
-                    out.warns.push_back(warn);
-                }
-                if (ok) out.vars.push_back(std::move(v));
+                else if (skip == Skip::UNSUPPORTED_SV) { out.st.total_variants++; out.st.skipped_unsupported_sv++; }
+                pos = nl ? end + 1 : vcf_n;
             }
         };
         unsigned nt = 1;
@@ -500,25 +532,38 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
             cut[t] = nl ? static_cast<size_t>(nl - vcf) + 1 : vcf_n;
             if (g == 0) cut[t] = 0;                            // position 0 is a line start itself
         }
-        std::vector<Part> parts(nt);
+        parts.resize(nt);
         if (nt == 1) parse_range(0, vcf_n, parts[0]);
         else {
             std::vector<std::thread> th;
             for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { parse_range(cut[t], cut[t + 1], parts[t]); });
             for (auto& x : th) x.join();
         }
-        size_t total = 0;
-        for (auto& pt : parts) total += pt.vars.size();
-        vars.reserve(total);
-        for (auto& pt : parts) {
+        part_base.assign(nt + 1, 0);
+        for (unsigned t = 0; t < nt; t++) {
+            const VcfPart& pt = parts[t];
+            part_base[t + 1] = part_base[t] + pt.size();
             stats.total_variants += pt.st.total_variants; stats.processed_variants += pt.st.processed_variants;
             stats.skipped_malformed += pt.st.skipped_malformed; stats.skipped_unsupported_sv += pt.st.skipped_unsupported_sv;
             for (const auto& w : pt.warns) fprintf(stderr, "%s\n", w.c_str());   // the reference warns on stderr (:301-302)
-            for (auto& v : pt.vars) vars.push_back(std::move(v));
         }
-        std::sort(vars.begin(), vars.end(), [](const HostVariant& a, const HostVariant& b) { return a.pos < b.pos; });
+        if (part_base[nt] >= 0xffffffffull) throw FormatError("VCF has too many records for this build");
+        // std::sort's permutation depends only on the outcomes of its comparisons, so sorting (pos, index)
+        // pairs by pos ends in the order the reference's sort of whole records ends in
+        order.resize(part_base[nt]);
+        for (unsigned t = 0; t < nt; t++)
+            for (size_t i = 0; i < parts[t].size(); i++) order[part_base[t] + i] = {parts[t].pos[i], (u32)(part_base[t] + i)};
+        std::sort(order.begin(), order.end(),
+                  [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& b) { return a.first < b.first; });
     }
-    const u64 nrec = vars.size();
+    // record j of the sorted order -> (part, index in part)
+    auto locate = [&](u64 j, const VcfPart*& pt) -> size_t {
+        const u64 g = order[j].second;
+        size_t t = std::upper_bound(part_base.begin(), part_base.end(), g) - part_base.begin() - 1;
+        pt = &parts[t];
+        return (size_t)(g - part_base[t]);
+    };
+    const u64 nrec = order.size();
 
     // a reference with an empty first line has no addressable positions; the reference divides by
     // line_width (UB), refuse instead
@@ -559,23 +604,50 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     HapArrays ha{};
     if (nrec) {
         // ---- records -> SoA
+        // two passes: sizes -> offsets (serial prefix sums), then the fill by several host threads
         std::vector<u64> hstart(nrec), hreflen(nrec), halt0(nrec + 1), hpair0(nrec + 1);
-        std::vector<u64> haltoff{0}, hpa0;
-        std::vector<uint8_t> haltchars;
-        std::vector<int> halleles;
+        std::vector<u64> altc0(nrec + 1), gtc0(nrec + 1);        // first alt char / first allele of record j
+        halt0[0] = 0; hpair0[0] = 0; altc0[0] = 0; gtc0[0] = 0;
         for (u64 j = 0; j < nrec; j++) {
-            const HostVariant& v = vars[j];
-            hstart[j] = v.pos - 1;                             // wraps for POS 0 like the reference's size_t
-            hreflen[j] = v.ref.size();
-            halt0[j] = haltoff.size() - 1;
-            for (const auto& al : v.alts) { haltchars.insert(haltchars.end(), al.begin(), al.end()); haltoff.push_back(haltchars.size()); }
-            hpair0[j] = hpa0.size();
-            for (const auto& gt : v.gts) { hpa0.push_back(halleles.size()); halleles.insert(halleles.end(), gt.begin(), gt.end()); }
-            max_samples = std::max<u64>(max_samples, v.gts.size());
+            const VcfPart* pt;
+            const size_t i = locate(j, pt);
+            const u64 na = pt->alt0[i + 1] - pt->alt0[i], ng = pt->gt0[i + 1] - pt->gt0[i];
+            halt0[j + 1] = halt0[j] + na;
+            hpair0[j + 1] = hpair0[j] + ng;
+            altc0[j + 1] = altc0[j] + (pt->altoff[pt->alt0[i + 1]] - pt->altoff[pt->alt0[i]]);
+            gtc0[j + 1] = gtc0[j] + (pt->gtoff[pt->gt0[i + 1]] - pt->gtoff[pt->gt0[i]]);
+            max_samples = std::max<u64>(max_samples, ng);
         }
-        halt0[nrec] = haltoff.size() - 1;
-        hpair0[nrec] = hpa0.size();
-        hpa0.push_back(halleles.size());
+        std::vector<u64> haltoff(halt0[nrec] + 1), hpa0(hpair0[nrec] + 1);
+        std::vector<uint8_t> haltchars(altc0[nrec]);
+        std::vector<int> halleles(gtc0[nrec]);
+        haltoff[halt0[nrec]] = altc0[nrec];
+        hpa0[hpair0[nrec]] = gtc0[nrec];
+        {
+            const unsigned hc = std::thread::hardware_concurrency();
+            const unsigned ft = nrec >= 65536 ? std::max(1u, std::min(16u, hc ? hc : 4u)) : 1u;
+            auto fill = [&](u64 lo, u64 hi) {
+                for (u64 j = lo; j < hi; j++) {
+                    const VcfPart* pt;
+                    const size_t i = locate(j, pt);
+                    hstart[j] = pt->pos[i] - 1;                    // wraps for POS 0 like the reference's size_t
+                    hreflen[j] = pt->reflen[i];
+                    const u64 a0 = pt->alt0[i], a1 = pt->alt0[i + 1], cbase = pt->altoff[a0];
+                    for (u64 a = a0; a < a1; a++) haltoff[halt0[j] + (a - a0)] = altc0[j] + (pt->altoff[a] - cbase);
+                    if (pt->altoff[a1] > cbase) memcpy(haltchars.data() + altc0[j], pt->altchars.data() + cbase, pt->altoff[a1] - cbase);
+                    const u64 g0 = pt->gt0[i], g1 = pt->gt0[i + 1], ebase = pt->gtoff[g0];
+                    for (u64 g = g0; g < g1; g++) hpa0[hpair0[j] + (g - g0)] = gtc0[j] + (pt->gtoff[g] - ebase);
+                    if (pt->gtoff[g1] > ebase)
+                        memcpy(halleles.data() + gtc0[j], pt->alleles.data() + ebase, sizeof(int) * (pt->gtoff[g1] - ebase));
+                }
+            };
+            if (ft == 1) fill(0, nrec);
+            else {
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < ft; t++) th.emplace_back(fill, nrec * t / ft, nrec * (t + 1) / ft);
+                for (auto& x : th) x.join();
+            }
+        }
         upload(start_, hstart, st); upload(reflen_, hreflen, st); upload(alt0_, halt0, st); upload(altoff_, haltoff, st);
         upload(altchars_, haltchars, st); upload(pair0_, hpair0, st); upload(pa0_, hpa0, st); upload(alleles_, halleles, st);
         d.start = start_.as<u64>(); d.reflen = reflen_.as<u64>(); d.alt0 = alt0_.as<u64>(); d.altstr_off = altoff_.as<u64>();
@@ -621,7 +693,7 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
             u64 off = 0;
             for (u64 v = r0v[0]; v < r0v[1]; v++) {
                 off = hstart[v] - gsv[0];
-                if (off > sp[0] && !vars[v].alts.empty()) break;
+                if (off > sp[0] && halt0[v + 1] > halt0[v]) break;
             }
             throw FormatError("basic_string::substr: __pos (which is " + std::to_string(off) + ") > this->size() (which is " +
                               std::to_string(sp[0]) + ")");
