@@ -2222,9 +2222,14 @@ void MsaPipeline::plan_body(hipStream_t st)
     seg_lds_ = (size_t)18 * S + 64 + (S <= HT_MAX_ROWS ? HtLds::BYTES + 16 : 0);
     seg_lds_ = (seg_lds_ + 15) & ~(size_t)15;
     stage_off_ = 0;
-    if (S <= 1024) {                                      // room for STAGE_COLS columns of the segment in LDS
-        stage_off_ = (u32)seg_lds_;
-        seg_lds_ += (size_t)STAGE_COLS * 8 + (size_t)STAGE_COLS * Spad;
+    stage_cols_ = 0;
+    {                                                     // as many columns of a segment as fit beside that (<= STAGE_COLS)
+        const size_t budget = (size_t)150 * 1024;
+        if (seg_lds_ + 4 * ((size_t)Spad + 8) <= budget) {
+            stage_cols_ = (u32)std::min<size_t>(STAGE_COLS, (budget - seg_lds_) / ((size_t)Spad + 8));
+            stage_off_ = (u32)seg_lds_;
+            seg_lds_ += (size_t)stage_cols_ * 8 + (size_t)stage_cols_ * Spad;
+        }
     }
 
     const u64 tok_total = token_total((u32)S);
@@ -2232,7 +2237,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     SegParams sp;
     sp.mv = mv_; sp.seg_start = seg_start; sp.nseg_ptr = d_nseg; sp.eds_len = eds_len_.as<u64>();
     sp.seds_len = seds_len_.as<u64>(); sp.tok_total = tok_total; sp.list = nullptr; sp.list_n = nullptr;
-    sp.stage_cols = stage_off_ ? STAGE_COLS : 0; sp.stage_off = stage_off_;
+    sp.stage_cols = stage_cols_; sp.stage_off = stage_off_;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_count),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     if (fast_) {
@@ -2348,7 +2353,7 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
     ep.eds_off = eds_len_.as<u64>(); ep.seds_off = seds_len_.as<u64>(); ep.eds = d_eds; ep.seds = d_seds;
     ep.nwords = h_.nwords;
     ep.list = nullptr; ep.list_n = nullptr;
-    ep.stage_cols = stage_off_ ? STAGE_COLS : 0; ep.stage_off = stage_off_;
+    ep.stage_cols = stage_cols_; ep.stage_off = stage_off_;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_emit_variant),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     if (fast_) {

@@ -138,7 +138,7 @@ private:
     const u64* seg_start_p_ = nullptr; const u64* hseg_p_ = nullptr; const u64* segbase_p_ = nullptr;
     const u64* nseg_p_ = nullptr;
     size_t seg_lds_ = 0;
-    u32 stage_off_ = 0;           // generic kernels: offset of the column staging area in their LDS (0: none)
+    u32 stage_off_ = 0, stage_cols_ = 0;   // generic kernels: column staging area in their LDS (offset, capacity; 0: none)
     bool fast_ = false;
     FastParams fp_{};
     int cus_ = 0;
