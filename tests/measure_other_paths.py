@@ -2,10 +2,10 @@
 """Wall-clock of the EDS -> l-EDS merge and the VCF -> EDS overlay through the C ABI (host bytes in, host
 bytes out: host tokeniser + device rounds + materialisation) beside the CPU oracle on the same host,
 with byte-equality of the two outputs checked.  Inputs: genrandomeds-shaped EDS (+ sEDS) and a
-BASELINE-C4-shaped VCF at reduced scale.  Usage: python3 profiles/other_paths.py [eds_mb] [vcf_k]"""
+BASELINE-C4-shaped VCF at reduced scale.  Usage: python3 tests/measure_other_paths.py [eds_mb] [vcf_k]"""
 import os, sys, time, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # the oracle is test infrastructure: this script lives under tests/
 import torch, edsparser_amd
 import oracle_lib as o
 
