@@ -51,14 +51,6 @@ __device__ __forceinline__ uint4 load16u(const uint8_t* p)
     __builtin_memcpy(&v, p, 16);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
-// the same with the non-temporal hint: the alignment matrix is read exactly once
-typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
-typedef v4u_t v4u_unaligned_t __attribute__((aligned(1)));
-__device__ __forceinline__ uint4 load16u_nt(const uint8_t* p)
-{
-    v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_unaligned_t*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
 // partial load of n (<16) bytes, zero padded
 __device__ __forceinline__ uint4 load_partial(const uint8_t* p, int n)
 {

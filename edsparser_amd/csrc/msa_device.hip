@@ -2,9 +2,11 @@
 // this is byte/bit work bounded by HBM bandwidth.
 //
 // Replaces the reference's three passes (src/cpp/lib/transforms/msa_transforms.cpp):
-//   pass 1 parse_msa_and_build_variant_bv :36-90   -> k_find_*/k_index_rows + k_scan_extract
+//   pass 1 parse_msa_and_build_variant_bv :36-90   -> k_find_*, k_index_spec/_check/_rows + k_scan_extract
 //   pass 2 build_eds/leds_boundaries      :101-190 -> k_runstart_words .. k_write_segs
-//   pass 3 generate_output                :200-324 -> k_seg_count, scans, k_emit_common, k_emit_variant
+//   pass 3 generate_output                :200-324 -> k_seg_meta, k_seg_count_fast (wave per segment, S <= 1024)
+//                                                     / k_seg_count (workgroup per segment), scans,
+//                                                     k_emit_common, k_emit_variant_fast / k_emit_variant
 //
 // Data layout in HBM
 //   file image    the FASTA bytes as given (no repacking).  Row r's raw byte q lives at
@@ -20,6 +22,8 @@
 //                 matrix is read from HBM exactly once.
 //   run/seg table seg_start[nseg+1] (alignment columns), bitmap Hseg of segment starts with a
 //                 per-word prefix segbase[]; a segment is common iff V[seg_start] == 0.
+//   grec          one grouping record per variant segment (count -> emit): group id of every row (one
+//                 byte, lane-major like vc), representative row and letter of every group, k.
 //   eds_off/seds_off  exclusive scans of the per-segment text sizes.
 #include "msa_device.hpp"
 
@@ -294,17 +298,6 @@ template <int I> __device__ __forceinline__ u32 byte_at(const uint4& v)
     return (w >> ((I & 3) * 8)) & 0xffu;
 }
 
-#ifndef EDSX_TILEMAP
-#define EDSX_TILEMAP 0
-#endif
-#ifndef EDSX_TILEGROUP
-#define EDSX_TILEGROUP 8
-#endif
-#ifdef EDSX_K1_NT
-#define EDSX_K1_LOAD load16u_nt
-#else
-#define EDSX_K1_LOAD load16u
-#endif
 template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW>
 __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 {
@@ -324,19 +317,10 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     u64 tile;
     {
         const u64 nt = p.ntiles, b = blockIdx.x;
-#if EDSX_TILEMAP == 1
-        // groups of G consecutive tiles per XCD, the 8 XCDs side by side: neighbouring tiles still share
-        // an L2, and all XCDs touch the same pages / DRAM rows at about the same time
-        constexpr u64 G = EDSX_TILEGROUP;
-        const u64 x = b % 8, k = b / 8;
-        const u64 full = nt / (8 * G) * (8 * G);
-        if (b < full) tile = (k / G) * (8 * G) + x * G + (k % G);
-        else tile = b;
-#else
+        // (interleaving the XCDs' tile ranges instead, or plain blockIdx order, measured the same)
         const u64 per = nt / 8, rem = nt % 8;     // XCD x owns per (+1 if x < rem) tiles
         const u64 x = b % 8, k = b / 8;
         tile = x * per + (x < rem ? x : rem) + k;
-#endif
     }
     const u64 q0 = tile * (u64)(cpr * 16);
     const u64 q = q0 + (u64)j * 16;
@@ -369,7 +353,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 #pragma unroll
         for (int it = 0; it < RPT; it++) {
             const u32 r = row_of(it);
-            d[HOLD ? it : 0] = EDSX_K1_LOAD(f + rs[r < p.S ? r : Sm1] + q);   // clamped: rows past S re-read row S-1
+            d[HOLD ? it : 0] = load16u(f + rs[r < p.S ? r : Sm1] + q);   // clamped: rows past S re-read row S-1
             if constexpr (!HOLD) {
                 acc.x |= d[0].x ^ ref.x; acc.y |= d[0].y ^ ref.y; acc.z |= d[0].z ^ ref.z; acc.w |= d[0].w ^ ref.w;
             }
@@ -2144,15 +2128,15 @@ void MsaPipeline::plan_body(hipStream_t st)
     //   cfg 1: T=512  RPT=16  (2 workgroups/CU)
     //   cfg 2: T=1024 RPT=8   (2 workgroups/CU, <= 64 VGPRs)
     static int cfg_env = -1;
-    if (cfg_env < 0) { const char* e = getenv("EDSX_K1"); cfg_env = e ? atoi(e) : 1; if (cfg_env < 0 || cfg_env > 3) cfg_env = 1; }
+    if (cfg_env < 0) { const char* e = getenv("EDSX_K1"); cfg_env = e ? atoi(e) : 1; if (cfg_env < 0 || cfg_env > 2) cfg_env = 1; }
     int cfg = cfg_env;
-    const int T = (cfg == 1 || cfg == 3) ? 512 : 1024, RPT = cfg == 2 ? 8 : 16;
+    const int T = cfg == 1 ? 512 : 1024, RPT = cfg == 2 ? 8 : 16;
     u32 cpr_log2 = 8;
     while (cpr_log2 > 2 && (u64)RPT * (T >> cpr_log2) < S) cpr_log2--;
     const bool hold = (u64)RPT * (T >> cpr_log2) >= S;
     const u64 W = 16ull << cpr_log2;
     const u64 ntiles = (Draw + W - 1) / W;
-    const size_t colbuf_bytes = cfg == 0 ? 96 * 1024 : (cfg == 3 ? 48 * 1024 : 64 * 1024);
+    const size_t colbuf_bytes = cfg == 0 ? 96 * 1024 : 64 * 1024;
     if (ntiles > 0x7fffffffull) throw FormatError("MSA too large for one launch");
     if (colbuf_bytes < (size_t)S * 8) throw FormatError(status_message(ST_TOO_MANY_ROWS));
 
@@ -2168,10 +2152,6 @@ void MsaPipeline::plan_body(hipStream_t st)
         if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
         else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
         else launch_k1<512, 16, false, false, 4>(kp, colbuf_bytes, st);
-    } else if (cfg == 3) {                                   // 3 workgroups / CU: <= 84 VGPRs
-        if (lane_rows) launch_k1<512, 16, true, true, 6>(kp, colbuf_bytes, st);
-        else if (hold) launch_k1<512, 16, true, false, 6>(kp, colbuf_bytes, st);
-        else launch_k1<512, 16, false, false, 6>(kp, colbuf_bytes, st);
     } else if (cfg == 2) {
         if (hold) launch_k1<1024, 8, true, false, 8>(kp, colbuf_bytes, st);
         else launch_k1<1024, 8, false, false, 8>(kp, colbuf_bytes, st);
