@@ -158,8 +158,15 @@ class SlabStitcher:
                 action.extra_eds += e
                 action.extra_seds += s
         e_lo, e_hi, s_lo, s_hi = piece_bounds(my, action)
-        sizes = [None] * self.world
-        self.dist.all_gather_object(sizes, ((e_hi - e_lo) + len(action.extra_eds), (s_hi - s_lo) + len(action.extra_seds)))
+        if any(ch.variant for ch in plan.chains):
+            sizes = [None] * self.world
+            self.dist.all_gather_object(sizes, ((e_hi - e_lo) + len(action.extra_eds), (s_hi - s_lo) + len(action.extra_seds)))
+        else:
+            # no recomputed segment anywhere: every rank derives all piece sizes from the gathered edges
+            sizes = []
+            for r in range(self.world):
+                b = piece_bounds(gathered[r], plan.actions[r])
+                sizes.append((b[1] - b[0], b[3] - b[2]))
         self.last = {
             "action": action, "eds_range": (e_lo, e_hi), "seds_range": (s_lo, s_hi),
             "eds_offset": sum(x[0] for x in sizes[:self.rank]), "seds_offset": sum(x[1] for x in sizes[:self.rank]),
