@@ -116,9 +116,12 @@ struct GrpArrays {
     u64* err;                                // [0] first failing group, [1] offset, [2] span length
 };
 
+// apply_variant_to_span :356-390: span.substr(0, off) + alt + (off + |ref| < |span| ? span.substr(off + |ref|) : "").
+// substr(0, n) never throws: an offset beyond the span (records at or below POS 0 with a long REF, groups
+// past the end of the reference) just takes the whole span; off + reflen wraps like the reference's size_t.
 __device__ __forceinline__ u64 hap_len(u64 off, u64 altlen, u64 reflen, u64 spanlen)
 {
-    u64 len = off + altlen;
+    u64 len = (off < spanlen ? off : spanlen) + altlen;
     if (off + reflen < spanlen) len += spanlen - (off + reflen);
     return len;
 }
@@ -140,10 +143,6 @@ __global__ void k_grp_count(VcfDev d, GrpArrays a)
         for (u64 v = r0; v < r1; v++) {
             const u64 off = d.start[v] - gs;
             const u64 nalt = d.alt0[v + 1] - d.alt0[v];
-            if (off > spanlen && nalt) {                       // span.substr(0, off) throws (:375)
-                if (atomicMin(&a.err[0], g) > g) { /* recorded below by the winning group */ }
-                break;
-            }
             for (u64 x = d.alt0[v]; x < d.alt0[v + 1]; x++)
                 chars += hap_len(off, d.altstr_off[x + 1] - d.altstr_off[x], d.reflen[v], spanlen);
             nraw += nalt;
@@ -183,7 +182,8 @@ __global__ void k_grp_haps(VcfDev d, GrpArrays a, HapArrays h)
                 const u64 len = hap_len(off, al, rl, spanlen);
                 h.rawlen[hi] = len; h.rawoff[hi] = co;
                 uint8_t* dst = h.hapchars + co;
-                for (u64 i = 0; i < off; i++) *dst++ = span[i];
+                const u64 pre = off < spanlen ? off : spanlen;
+                for (u64 i = 0; i < pre; i++) *dst++ = span[i];
                 for (u64 i = 0; i < al; i++) *dst++ = d.altchars[d.altstr_off[x] + i];
                 if (off + rl < spanlen) for (u64 i = off + rl; i < spanlen; i++) *dst++ = span[i];
                 co += len; hi++;
@@ -657,9 +657,29 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
         ends_.ensure(8 * (nrec + 2)); flag_.ensure(8 * (nrec + 2)); gidx_.ensure(8 * (nrec + 2)); grp_r0_.ensure(8 * (nrec + 2));
         hctl[0] = nrec;
         EDSX_HIP(hipMemcpyAsync(ctl, hctl, 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_rec_ends, dim3(1024), dim3(256), 0, st, d.start, d.reflen, nrec, ends_.as<u64>());
-        inclusive_max_scan_u64(ends_.as<u64>(), ends_.as<u64>(), ctl + 0, ctl + 2, scan_tmp_.as<u64>(), st);
-        hipLaunchKernelGGL(k_mark_groups, dim3(1024), dim3(256), 0, st, d.start, ends_.as<u64>(), nrec, flag_.as<u64>());
+        // The parallel rule "a record opens a group iff its start is not below the largest end seen so far" equals
+        // the reference's sweep (:482-534, group_end restarts with every group) as long as starts ascend with the
+        // sort key and no end wraps.  POS 0 (start = 2^64 - 1) or POS near 2^64 ("-5" parses!) break that; such
+        // files are swept on the host exactly as the reference does it (running group end per record).
+        bool wraps = false;
+        for (u64 j = 0; j < nrec && !wraps; j++) wraps = hstart[j] == ~0ull || hstart[j] + hreflen[j] < hstart[j];
+        if (!wraps) {
+            hipLaunchKernelGGL(k_rec_ends, dim3(1024), dim3(256), 0, st, d.start, d.reflen, nrec, ends_.as<u64>());
+            inclusive_max_scan_u64(ends_.as<u64>(), ends_.as<u64>(), ctl + 0, ctl + 2, scan_tmp_.as<u64>(), st);
+            hipLaunchKernelGGL(k_mark_groups, dim3(1024), dim3(256), 0, st, d.start, ends_.as<u64>(), nrec, flag_.as<u64>());
+        } else {
+            std::vector<u64> hflag(nrec), hend(nrec);
+            u64 ge = 0;
+            for (u64 j = 0; j < nrec; j++) {
+                const u64 e = hstart[j] + hreflen[j];
+                if (j == 0 || !(hstart[j] < ge)) { hflag[j] = 1; ge = e; }
+                else { hflag[j] = 0; ge = std::max(ge, e); }
+                hend[j] = ge;
+            }
+            EDSX_HIP(hipMemcpyAsync(flag_.ptr, hflag.data(), 8 * nrec, hipMemcpyHostToDevice, st));
+            EDSX_HIP(hipMemcpyAsync(ends_.ptr, hend.data(), 8 * nrec, hipMemcpyHostToDevice, st));
+            EDSX_HIP(hipStreamSynchronize(st));                    // the vectors go out of scope
+        }
         exclusive_scan_u64(flag_.as<u64>(), gidx_.as<u64>(), ctl + 0, ctl + 3, scan_tmp_.as<u64>(), st);
         hipLaunchKernelGGL(k_group_firsts, dim3(1024), dim3(256), 0, st, flag_.as<u64>(), gidx_.as<u64>(), nrec,
                            grp_r0_.as<u64>(), ctl + 3);
@@ -683,21 +703,6 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
         exclusive_scan_u64(ga.rawchars, rawc0_.as<u64>(), ctl + 0, ctl + 5, scan_tmp_.as<u64>(), st);
         EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
         EDSX_HIP(hipStreamSynchronize(st));
-        if (hctl[10] != ~0ull) {
-            // the reference dies in std::string::substr inside apply_variant_to_span (:375); rebuild its message
-            const u64 g = hctl[10];
-            std::vector<u64> r0v(2), sp(1), gsv(1);
-            EDSX_HIP(hipMemcpy(r0v.data(), grp_r0_.as<u64>() + g, 16, hipMemcpyDeviceToHost));
-            EDSX_HIP(hipMemcpy(sp.data(), g_spanlen_.as<u64>() + g, 8, hipMemcpyDeviceToHost));
-            EDSX_HIP(hipMemcpy(gsv.data(), g_gs_.as<u64>() + g, 8, hipMemcpyDeviceToHost));
-            u64 off = 0;
-            for (u64 v = r0v[0]; v < r0v[1]; v++) {
-                off = hstart[v] - gsv[0];
-                if (off > sp[0] && halt0[v + 1] > halt0[v]) break;
-            }
-            throw FormatError("basic_string::substr: __pos (which is " + std::to_string(off) + ") > this->size() (which is " +
-                              std::to_string(sp[0]) + ")");
-        }
         const u64 nraw_total = hctl[4], rawchars_total = hctl[5];
         const u32 sw = (u32)std::max<u64>(1, (max_samples + 63) / 64);
         rawlen_.ensure(8 * (nraw_total + 2)); rawoff_.ensure(8 * (nraw_total + 2)); canon_.ensure(4 * (nraw_total + 2));

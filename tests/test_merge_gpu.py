@@ -150,3 +150,34 @@ def test_parallel_tokenisers_large_inputs(ctx, compact_in):
     except o.OracleError as ex:
         got = _run(ctx, eds, bad_s, 5, True)
         assert got.get("error") == str(ex)
+
+
+def test_parallel_tokenisers_fuzz(ctx):
+    """Random damage to large .eds/.seds inputs (bytes inserted, deleted or replaced anywhere): whatever
+    the chunk-parallel tokenisers make of it, result or error text must equal the oracle's (= the
+    reference's sequential parser)."""
+    rng = random.Random(2024)
+    eds0, seds0 = _big_eds(rng, 140000, 5, False, 40)
+    junk = b"{},AC \n0123x{{}}"
+    for it in range(24):
+        eds, seds = bytearray(eds0), bytearray(seds0)
+        target = eds if it % 2 == 0 else seds
+        for _ in range(rng.randint(1, 3)):
+            pos = rng.randrange(len(target))
+            op = rng.random()
+            if op < 0.4:
+                target[pos:pos] = bytes([rng.choice(junk)])
+            elif op < 0.7:
+                del target[pos]
+            else:
+                target[pos] = rng.choice(junk)
+        eds, seds = bytes(eds), bytes(seds)
+        sd = seds if it % 3 else None
+        try:
+            want = o.merge(eds, sd, 6, True)
+            want = {"out": want[0].decode(), "seds_out": want[1].decode()}
+        except o.OracleError as ex:
+            want = {"error": str(ex)}
+        got = _run(ctx, eds, sd, 6, True)
+        got.pop("code", None)
+        assert got == want, it

@@ -102,3 +102,46 @@ def test_multithreaded_tokeniser_large_vcf(ctx):
     assert len(vcf) >= 4 << 20
     e, s, st = o.vcf(vcf, fasta, 0)
     assert _run(ctx, vcf, fasta, 0) == {"eds": e.decode(), "seds": s.decode(), "stats": st}
+
+
+def test_multithreaded_tokeniser_fuzz(ctx):
+    """Random damage to a large VCF (tabs turned into spaces, fields removed, junk lines, odd genotypes,
+    symbolic alleles, CR line ends): records, counters and output must equal the oracle's."""
+    rng = random.Random(4242)
+    vcf0, fasta = _random_vcf(rng, 300000, 36000, 24, 60)
+    lines0 = vcf0.decode().split("\n")
+    assert len(vcf0) >= 4 << 20
+    for it in range(8):
+        lines = list(lines0)
+        for _ in range(400):
+            i = rng.randrange(2, len(lines) - 1)
+            f = lines[i].split("\t")
+            op = rng.randrange(9)
+            if op == 0:
+                lines[i] = lines[i].replace("\t", " ")
+            elif op == 1 and len(f) > 6:
+                lines[i] = "\t".join(f[:rng.randint(1, 6)])
+            elif op == 2:
+                lines[i] = rng.choice(["", "#junk", "chr1", "\t\t\t", "chr1\t12\t.\tA"])
+            elif op == 3 and len(f) > 10:
+                f[9 + rng.randrange(len(f) - 9)] = rng.choice(["./.", ".", "1", "0/1/2", "x|1", "1|", "|", "0|1:9:x", "", "99999999999|0"])
+                lines[i] = "\t".join(f)
+            elif op == 4 and len(f) > 5:
+                f[4] = rng.choice(["<DEL>", "<INS>", "<INV>", "A,<DEL>", "<DUP>,C", ",", "A,,C", "C,", "<>", "<", "."])
+                lines[i] = "\t".join(f)
+            elif op == 5:
+                lines[i] = lines[i] + "\r"
+            elif op == 6 and len(f) > 2:
+                f[1] = rng.choice(["0", "-5", "+7", " 12", "12abc", "abc", "", "99999999999999999999999", "300001"])
+                lines[i] = "\t".join(f)
+            elif op == 7:
+                lines[i] = lines[i].replace("\t", "\t\t", 2)
+            else:
+                lines.insert(i, lines[rng.randrange(2, len(lines) - 1)])
+        vcf = "\n".join(lines).encode()
+        try:
+            e, s, st = o.vcf(vcf, fasta, 0)
+            want = {"eds": e.decode(), "seds": s.decode(), "stats": st}
+        except o.OracleError as ex:
+            want = {"error": str(ex)}
+        assert _run(ctx, vcf, fasta, 0) == want, it
