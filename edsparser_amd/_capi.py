@@ -68,6 +68,12 @@ def load_library():
                                     ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, P(_Buf), P(_Buf)]
     lib.edsx_vcf_transform.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                        ctypes.c_size_t, ctypes.c_uint32, P(_Buf), P(_Buf), P(VcfStats)]
+    lib.edsx_vcf_index.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, P(_Buf), P(_Buf), P(_Buf), P(_Buf),
+                                   P(VcfStats)]
+    lib.edsx_vcf_sort_order.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.edsx_vcf_transform_range.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                             ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64, P(_Buf), P(_Buf),
+                                             P(VcfStats)]
     lib.edsx_msa_plan_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
                                          ctypes.c_void_p, P(ctypes.c_uint64), P(ctypes.c_uint64)]
     lib.edsx_msa_emit_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -143,6 +149,35 @@ class Context:
         vcf, fasta = bytes(vcf), bytes(fasta)
         self._check(self._lib.edsx_vcf_transform(self._h, vcf, len(vcf), fasta, len(fasta), context_len,
                                                  ctypes.byref(e), ctypes.byref(s), ctypes.byref(st)))
+        return self._take(e), self._take(s), {n: int(getattr(st, n)) for n, _ in VcfStats._fields_}
+
+    # ---- position-range partition of the VCF path (multi-GPU, see multigpu.VcfSharder)
+    def vcf_index(self, vcf):
+        """(pos, reflen, line_off, line_len) as numpy uint64 arrays, file order, + counters."""
+        import numpy as np
+        bufs = [_Buf() for _ in range(4)]
+        st = VcfStats()
+        vcf = bytes(vcf)
+        self._check(self._lib.edsx_vcf_index(self._h, vcf, len(vcf), *[ctypes.byref(b) for b in bufs], ctypes.byref(st)))
+        arrs = [np.frombuffer(self._take(b), dtype=np.uint64) for b in bufs]
+        return (*arrs, {n: int(getattr(st, n)) for n, _ in VcfStats._fields_})
+
+    def vcf_sort_order(self, pos):
+        """Permutation of the reference's std::sort for these positions (numpy uint64 -> uint32)."""
+        import numpy as np
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        out = np.empty(len(pos), dtype=np.uint32)
+        rc = self._lib.edsx_vcf_sort_order(pos.ctypes.data, len(pos), out.ctypes.data)
+        if rc != 0:
+            raise EdsxError(rc, "edsx_vcf_sort_order failed")
+        return out
+
+    def vcf_transform_range(self, vcf_lines, fasta, cur0=0, next_start=None):
+        e, s, st = _Buf(), _Buf(), VcfStats()
+        vcf_lines, fasta = bytes(vcf_lines), bytes(fasta)
+        nxt = 0xFFFFFFFFFFFFFFFF if next_start is None else int(next_start)
+        self._check(self._lib.edsx_vcf_transform_range(self._h, vcf_lines, len(vcf_lines), fasta, len(fasta), int(cur0),
+                                                       nxt, ctypes.byref(e), ctypes.byref(s), ctypes.byref(st)))
         return self._take(e), self._take(s), {n: int(getattr(st, n)) for n, _ in VcfStats._fields_}
 
     # ---- device-resident entry points (pointers are ints: tensor.data_ptr())

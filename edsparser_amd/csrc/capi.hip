@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace edsx;
 
@@ -211,6 +212,68 @@ int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, const
                            s.size(), context_len, true, lo, so, nullptr);
             e.swap(lo);
             s.swap(so);
+        }
+        take(eds, e.size());
+        std::memcpy(eds->data, e.data(), e.size());
+        take(seds, s.size());
+        std::memcpy(seds->data, s.data(), s.size());
+    });
+}
+
+namespace {
+void take_u64(edsx_buf* b, const std::vector<u64>& v)
+{
+    take(b, 8 * v.size());
+    if (!v.empty()) std::memcpy(b->data, v.data(), 8 * v.size());
+}
+} // namespace
+
+int edsx_vcf_index(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, edsx_buf* pos, edsx_buf* reflen, edsx_buf* line_off,
+                   edsx_buf* line_len, edsx_vcf_stats* stats)
+{
+    for (edsx_buf* b : {pos, reflen, line_off, line_len}) if (b) { b->data = nullptr; b->size = 0; }
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    return guarded(ctx, [&] {
+        if (!pos || !reflen || !line_off || !line_len || (!vcf && vcf_size)) throw ParamError("null argument");
+        static const uint8_t none = 0;
+        std::vector<u64> p, r, lo, ll;
+        VcfCounters c;
+        vcf_index(vcf ? vcf : &none, vcf_size, p, r, lo, ll, c);
+        if (stats) {
+            stats->total_variants = c.total_variants; stats->processed_variants = c.processed_variants;
+            stats->skipped_malformed = c.skipped_malformed; stats->skipped_unsupported_sv = c.skipped_unsupported_sv;
+        }
+        take_u64(pos, p); take_u64(reflen, r); take_u64(line_off, lo); take_u64(line_len, ll);
+    });
+}
+
+int edsx_vcf_sort_order(const uint64_t* pos, size_t n, uint32_t* order_out)
+{
+    if ((!pos || !order_out) && n) return EDSX_ERR_INVALID_PARAMETER;
+    if (n >= 0xffffffffull) return EDSX_ERR_INVALID_PARAMETER;
+    static_assert(sizeof(u64) == sizeof(uint64_t), "u64");
+    try { vcf_sort_order(reinterpret_cast<const u64*>(pos), n, order_out); } catch (...) { return EDSX_ERR_BUILD_FAILED; }
+    return EDSX_OK;
+}
+
+int edsx_vcf_transform_range(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, const uint8_t* fasta, size_t fasta_size,
+                             uint64_t cur0, uint64_t next_start, edsx_buf* eds, edsx_buf* seds, edsx_vcf_stats* stats)
+{
+    if (eds) { eds->data = nullptr; eds->size = 0; }
+    if (seds) { seds->data = nullptr; seds->size = 0; }
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    return guarded(ctx, [&] {
+        if (!eds || !seds || (!vcf && vcf_size) || (!fasta && fasta_size)) throw ParamError("null argument");
+        static const uint8_t none = 0;
+        std::string e, s;
+        VcfCounters c;
+        VcfRange range;
+        range.presorted = true; range.cur0 = cur0; range.next_start = next_start;
+        ctx->vcf.run(vcf ? vcf : &none, vcf_size, fasta ? fasta : &none, fasta_size, e, s, c, nullptr, range);
+        if (stats) {
+            stats->total_variants = c.total_variants; stats->processed_variants = c.processed_variants;
+            stats->skipped_malformed = c.skipped_malformed; stats->skipped_unsupported_sv = c.skipped_unsupported_sv;
+            stats->variant_groups = c.variant_groups;
         }
         take(eds, e.size());
         std::memcpy(eds->data, e.data(), e.size());

@@ -38,6 +38,7 @@ struct VcfDev {
     // groups
     u64 ngrp; const u64* grp_r0;   // first record of group g, grp_r0[ngrp] = nrec
     const u64* incl_end;           // inclusive max-scan of record ends
+    u64 cur0;                      // reference position the walk starts at (0 unless this is a later position range)
 };
 
 __device__ __forceinline__ u64 fa_cpos(const VcfDev& d, u64 file_off)
@@ -269,7 +270,7 @@ __global__ void k_grp_samples(VcfDev d, GrpArrays a, HapArrays h)
 __global__ void k_grp_common(VcfDev d, GrpArrays a)
 {
     for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < d.ngrp; g += (u64)gridDim.x * blockDim.x) {
-        const u64 cur = g ? a.cur_after[g - 1] : 0;
+        const u64 cur = g ? a.cur_after[g - 1] : d.cur0;
         const u64 gs = a.gs[g];
         u64 clen = 0;
         if (gs > cur && cur < d.seq_size) {
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(256) k_grp_emit(VcfDev d, GrpArrays a, HapArra
         uint8_t* so = e.seds + e.seds_off[g];
         const u64 clen = a.commonlen[g];
         if (clen) {
-            const u64 cur = g ? a.cur_after[g - 1] : 0;
+            const u64 cur = g ? a.cur_after[g - 1] : d.cur0;
             const u64 c0 = fa_cpos(d, d.seq_start + cur + cur / d.lw);
             if (lane == 0) { eo[0] = '{'; eo[clen + 1] = '}'; so[0] = '{'; so[1] = '0'; so[2] = '}'; }
             for (u64 i = lane; i < clen; i += 64) eo[1 + i] = d.refc[c0 + i];
@@ -374,6 +375,7 @@ struct VcfPart {
     std::vector<uint8_t> altchars;
     std::vector<u64> gt0{0}, gtoff{0};
     std::vector<int> alleles;
+    std::vector<u64> loff, llen;                             // line of every accepted record (index pass only)
     VcfCounters st;
     std::vector<std::string> warns;
     size_t size() const { return pos.size(); }
@@ -407,7 +409,7 @@ void parse_gt_flat(Span gt, VcfPart& out)
 }
 
 // parse_vcf_line :232-326 into the flat store; `fields` is scratch
-Skip parse_line_flat(const char* line, size_t n, VcfPart& out, std::vector<Span>& fields)
+Skip parse_line_flat(const char* line, size_t n, VcfPart& out, std::vector<Span>& fields, bool light = false)
 {
     if (n == 0 || line[0] == '#') return Skip::HEADER;
     fields.clear();
@@ -453,7 +455,7 @@ Skip parse_line_flat(const char* line, size_t n, VcfPart& out, std::vector<Span>
         } else { out.altchars.insert(out.altchars.end(), a, a + len); out.altoff.push_back(out.altchars.size()); }
         i = end + 1;
     }
-    if (fields.size() >= 10)
+    if (fields.size() >= 10 && !light)
         for (size_t f = 9; f < fields.size(); f++) {
             Span gt = fields[f];
             const char* c = static_cast<const char*>(memchr(gt.p, ':', gt.n));
@@ -474,10 +476,99 @@ template <class T> void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s
     if (!v.empty()) EDSX_HIP(hipMemcpyAsync(b.ptr, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, st));
 }
 
+// Lines are independent: large files are cut at line starts and tokenised by several host threads; records,
+// counters and the stderr warnings are put together in file order, so the array handed to std::sort is the
+// reference's.  light = positions, REF lengths and line spans only (the index pass of a partitioned run).
+void tokenise(const uint8_t* vcf, size_t vcf_n, std::vector<VcfPart>& parts, std::vector<u64>& part_base,
+              VcfCounters& stats, bool light)
+{
+    auto parse_range = [&](size_t lo, size_t hi, VcfPart& out) {
+        std::vector<Span> fields;
+        size_t pos = lo;
+        while (pos < hi && pos < vcf_n) {
+            const uint8_t* nl = static_cast<const uint8_t*>(memchr(vcf + pos, '\n', vcf_n - pos));
+            const size_t end = nl ? static_cast<size_t>(nl - vcf) : vcf_n;
+            const Skip skip = parse_line_flat(reinterpret_cast<const char*>(vcf + pos), end - pos, out, fields, light);
+            if (skip == Skip::NONE) {
+                out.st.total_variants++; out.st.processed_variants++;
+                if (light) { out.loff.push_back(pos); out.llen.push_back(end - pos); }
+            }
+            else if (skip == Skip::MALFORMED) { out.st.total_variants++; out.st.skipped_malformed++; }
+            else if (skip == Skip::UNSUPPORTED_SV) { out.st.total_variants++; out.st.skipped_unsupported_sv++; }
+            pos = nl ? end + 1 : vcf_n;
+        }
+    };
+    unsigned nt = 1;
+    if (vcf_n >= ((size_t)4 << 20)) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        nt = std::max(1u, std::min(16u, hc ? hc : 4u));
+    }
+    std::vector<size_t> cut(nt + 1, vcf_n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < nt; t++) {                        // first line start at or after t*n/nt
+        size_t g = (size_t)((unsigned __int128)vcf_n * t / nt);
+        if (g < cut[t - 1]) g = cut[t - 1];
+        const uint8_t* nl = g < vcf_n ? static_cast<const uint8_t*>(memchr(vcf + g, '\n', vcf_n - g)) : nullptr;
+        cut[t] = nl ? static_cast<size_t>(nl - vcf) + 1 : vcf_n;
+        if (g == 0) cut[t] = 0;                                // position 0 is a line start itself
+    }
+    parts.clear();
+    parts.resize(nt);
+    if (nt == 1) parse_range(0, vcf_n, parts[0]);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { parse_range(cut[t], cut[t + 1], parts[t]); });
+        for (auto& x : th) x.join();
+    }
+    part_base.assign(nt + 1, 0);
+    for (unsigned t = 0; t < nt; t++) {
+        const VcfPart& pt = parts[t];
+        part_base[t + 1] = part_base[t] + pt.size();
+        stats.total_variants += pt.st.total_variants; stats.processed_variants += pt.st.processed_variants;
+        stats.skipped_malformed += pt.st.skipped_malformed; stats.skipped_unsupported_sv += pt.st.skipped_unsupported_sv;
+        for (const auto& w : pt.warns) fprintf(stderr, "%s\n", w.c_str());   // the reference warns on stderr (:301-302)
+    }
+    if (part_base[nt] >= 0xffffffffull) throw FormatError("VCF has too many records for this build");
+}
+
+// the reference's std::sort call (:715-718) on (pos, file index) pairs
+void sort_like_reference(std::vector<std::pair<u64, u32>>& order)
+{
+    std::sort(order.begin(), order.end(),
+              [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& b) { return a.first < b.first; });
+}
+
 } // namespace
 
+// ---- index pass and sort order of a partitioned run (VCF row) ------------------------------
+void vcf_index(const uint8_t* vcf, size_t vcf_n, std::vector<u64>& pos, std::vector<u64>& reflen, std::vector<u64>& line_off,
+               std::vector<u64>& line_len, VcfCounters& stats)
+{
+    stats = VcfCounters();
+    std::vector<VcfPart> parts;
+    std::vector<u64> part_base;
+    tokenise(vcf, vcf_n, parts, part_base, stats, true);
+    const size_t n = part_base.back();
+    pos.clear(); reflen.clear(); line_off.clear(); line_len.clear();
+    pos.reserve(n); reflen.reserve(n); line_off.reserve(n); line_len.reserve(n);
+    for (const VcfPart& pt : parts) {
+        pos.insert(pos.end(), pt.pos.begin(), pt.pos.end());
+        reflen.insert(reflen.end(), pt.reflen.begin(), pt.reflen.end());
+        line_off.insert(line_off.end(), pt.loff.begin(), pt.loff.end());
+        line_len.insert(line_len.end(), pt.llen.begin(), pt.llen.end());
+    }
+}
+
+void vcf_sort_order(const u64* pos, size_t n, u32* order_out)
+{
+    std::vector<std::pair<u64, u32>> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = {pos[i], (u32)i};
+    sort_like_reference(order);
+    for (size_t i = 0; i < n; i++) order_out[i] = order[i].second;
+}
+
 void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, std::string& eds,
-                      std::string& seds, VcfCounters& stats, hipStream_t st)
+                      std::string& seds, VcfCounters& stats, hipStream_t st, const VcfRange& range)
 {
     stats = VcfCounters();
     // ---- FASTA metadata (:51-86)
@@ -498,63 +589,21 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
             seq_size += line.size();
         }
     }
-    // ---- VCF records (:690-712) and the unstable sort (:715-718).  Lines are independent: large files
-    // are cut at line starts and tokenised by several host threads; records, counters and the stderr
-    // warnings are put together in file order, so the array handed to std::sort is the reference's.
+    // ---- VCF records (:690-712) and the unstable sort (:715-718)
     std::vector<VcfPart> parts;
     std::vector<u64> part_base;                              // first global record index of every part
     std::vector<std::pair<u64, u32>> order;                  // (pos, global index in file order), sorted by pos
+    tokenise(vcf, vcf_n, parts, part_base, stats, false);
     {
-        auto parse_range = [&](size_t lo, size_t hi, VcfPart& out) {
-            std::vector<Span> fields;
-            size_t pos = lo;
-            while (pos < hi && pos < vcf_n) {
-                const uint8_t* nl = static_cast<const uint8_t*>(memchr(vcf + pos, '\n', vcf_n - pos));
-                const size_t end = nl ? static_cast<size_t>(nl - vcf) : vcf_n;
-                const Skip skip = parse_line_flat(reinterpret_cast<const char*>(vcf + pos), end - pos, out, fields);
-                if (skip == Skip::NONE) { out.st.total_variants++; out.st.processed_variants++; }
-                else if (skip == Skip::MALFORMED) { out.st.total_variants++; out.st.skipped_malformed++; }
-                else if (skip == Skip::UNSUPPORTED_SV) { out.st.total_variants++; out.st.skipped_unsupported_sv++; }
-                pos = nl ? end + 1 : vcf_n;
-            }
-        };
-        unsigned nt = 1;
-        if (vcf_n >= ((size_t)4 << 20)) {
-            const unsigned hc = std::thread::hardware_concurrency();
-            nt = std::max(1u, std::min(16u, hc ? hc : 4u));
-        }
-        std::vector<size_t> cut(nt + 1, vcf_n);
-        cut[0] = 0;
-        for (unsigned t = 1; t < nt; t++) {                    // first line start at or after t*n/nt
-            size_t g = (size_t)((unsigned __int128)vcf_n * t / nt);
-            if (g < cut[t - 1]) g = cut[t - 1];
-            const uint8_t* nl = g < vcf_n ? static_cast<const uint8_t*>(memchr(vcf + g, '\n', vcf_n - g)) : nullptr;
-            cut[t] = nl ? static_cast<size_t>(nl - vcf) + 1 : vcf_n;
-            if (g == 0) cut[t] = 0;                            // position 0 is a line start itself
-        }
-        parts.resize(nt);
-        if (nt == 1) parse_range(0, vcf_n, parts[0]);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { parse_range(cut[t], cut[t + 1], parts[t]); });
-            for (auto& x : th) x.join();
-        }
-        part_base.assign(nt + 1, 0);
-        for (unsigned t = 0; t < nt; t++) {
-            const VcfPart& pt = parts[t];
-            part_base[t + 1] = part_base[t] + pt.size();
-            stats.total_variants += pt.st.total_variants; stats.processed_variants += pt.st.processed_variants;
-            stats.skipped_malformed += pt.st.skipped_malformed; stats.skipped_unsupported_sv += pt.st.skipped_unsupported_sv;
-            for (const auto& w : pt.warns) fprintf(stderr, "%s\n", w.c_str());   // the reference warns on stderr (:301-302)
-        }
-        if (part_base[nt] >= 0xffffffffull) throw FormatError("VCF has too many records for this build");
+        const unsigned nt = (unsigned)parts.size();
         // std::sort's permutation depends only on the outcomes of its comparisons, so sorting (pos, index)
         // pairs by pos ends in the order the reference's sort of whole records ends in
         order.resize(part_base[nt]);
         for (unsigned t = 0; t < nt; t++)
             for (size_t i = 0; i < parts[t].size(); i++) order[part_base[t] + i] = {parts[t].pos[i], (u32)(part_base[t] + i)};
-        std::sort(order.begin(), order.end(),
-                  [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& b) { return a.first < b.first; });
+        // a position range of a partitioned run hands its records over in their final order (the order of the
+        // whole file's sort, edsx_vcf_sort_order): sorting the slice again could permute equal positions differently
+        if (!range.presorted) sort_like_reference(order);
     }
     // record j of the sorted order -> (part, index in part)
     auto locate = [&](u64 j, const VcfPart*& pt) -> size_t {
@@ -596,9 +645,9 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     VcfDev d{};
     d.fasta = d_fasta_.as<uint8_t>(); d.fasta_n = fasta_n; d.seq_start = seq_start; d.seq_size = seq_size; d.lw = lw;
     d.refc = refc_.as<uint8_t>(); d.refc_n = refc_n; d.blkpre = blkpre_.as<u64>();
-    d.nrec = nrec;
+    d.nrec = nrec; d.cur0 = range.cur0;
 
-    u64 cur = 0, ngrp = 0, E = 0, Q = 0;
+    u64 cur = range.cur0, ngrp = 0, E = 0, Q = 0;
     u64 max_samples = 0;
     GrpArrays ga{};
     HapArrays ha{};
@@ -726,10 +775,13 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
         E = hctl[7]; Q = hctl[8]; cur = last_cur;
     }
     // ---- tail (:658-665)
+    // A position range that is not the last one ends with what the reference flushes in front of the next
+    // range's first group instead (:570-578, `start > cur`, text clamped by read_fasta_region).
+    const bool last_range = range.next_start == ~0ull;
     u64 tail = 0;
-    if (cur < seq_size) {
+    if (cur < seq_size && (last_range || range.next_start > cur)) {
         // clamp exactly like read_fasta_region: by seq_size and by what the file still holds
-        u64 length = seq_size - cur;
+        u64 length = last_range ? seq_size - cur : std::min<u64>(range.next_start - cur, seq_size - cur);
         // position of `cur` in the newline-free stream: ask the device map (one thread)
         hipLaunchKernelGGL(k_cpos, dim3(1), dim3(1), 0, st, d, seq_start + cur + cur / lw, ctl + 11);
         u64 c0 = 0;

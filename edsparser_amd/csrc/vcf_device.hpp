@@ -4,6 +4,7 @@
 #include "msa_device.hpp"
 
 #include <string>
+#include <vector>
 
 namespace edsx {
 
@@ -11,11 +12,26 @@ struct VcfCounters {   // vcf_transforms.hpp:24-35
     u64 total_variants = 0, processed_variants = 0, skipped_malformed = 0, skipped_unsupported_sv = 0, variant_groups = 0;
 };
 
+// One position range of a partitioned run: the records are handed over in their final order, the
+// walk starts at cur0 (no common text in front of the first group when cur0 is its start) and the closing common
+// text stops at the first group of the next range.
+struct VcfRange {
+    bool presorted = false;
+    u64 cur0 = 0;
+    u64 next_start = ~0ull;        // ~0: last (or only) range, flush to the end of the reference
+};
+
+// index pass of a partitioned run: positions, REF lengths and line spans of the accepted records, file order
+void vcf_index(const uint8_t* vcf, size_t vcf_n, std::vector<u64>& pos, std::vector<u64>& reflen, std::vector<u64>& line_off,
+               std::vector<u64>& line_len, VcfCounters& stats);
+// permutation the reference's std::sort (vcf_transforms.cpp:715-718) gives an array with these positions
+void vcf_sort_order(const u64* pos, size_t n, u32* order_out);
+
 class VcfPipeline {
 public:
     // host buffers in; eds/seds text out (FULL brackets, no trailing newline, like the reference)
     void run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, std::string& eds, std::string& seds,
-             VcfCounters& stats, hipStream_t st);
+             VcfCounters& stats, hipStream_t st, const VcfRange& range = VcfRange());
 
 private:
     DevBuf d_fasta_, refc_, blkpre_, scan_tmp_, ctl_, start_, reflen_, alt0_, altoff_, altchars_, pair0_, pa0_, alleles_,

@@ -200,3 +200,179 @@ def gpu_stitcher(ctx, mini_ctx, rank, world, n_rows, cols, dist):
                       lambda c0, nc: ctx.msa_copy_columns(c0, nc, n_rows))
     st.set_sizes = lambda E, Q: setattr(get_edges, "sizes", (E, Q))
     return st
+
+
+# ======================================================================================================
+# VCF -> EDS over several GPUs: partition by reference position (BASELINE configs[3])
+# ======================================================================================================
+#
+# The reference groups records into maximal chains of overlapping records (vcf_transforms.cpp:482-534) and
+# walks the groups once, flushing the reference text between them (:554-668).  A cut placed at the first
+# record of a group is therefore free: the left range ends with exactly the common text the reference
+# flushes in front of that group, the right range starts with the group, and the pieces concatenate to the
+# reference's output byte for byte — no repair of text.  What is global is the *order* of the records: the
+# reference sorts the whole array with an unstable std::sort (:715-718), so equal positions land in an order
+# that depends on the whole array.  The exchange steps are therefore
+#
+#   1. every rank indexes its byte range of the VCF (POS, REF length, line spans; no genotypes),
+#   2. all-gather of the (POS, REF length) arrays — 16 B per record,
+#   3. every rank derives the same order (edsx_vcf_sort_order = that std::sort), group starts (running
+#      maximum of record ends, :510) and cuts (first group start at or after k * n / world),
+#   4. record lines whose position falls into another rank's range are exchanged as text (for a sorted
+#      VCF: only the slivers next to the byte cuts; everything of a shuffled file),
+#   5. every rank runs its range through edsx_vcf_transform_range on its own GPU,
+#   6. all-gather of the piece sizes for the output offsets.  The output stays sharded.
+#
+# Files with wrapped positions (POS 0 or near 2^64, see vcf_device.hip) are not partitioned: rank 0 takes
+# all records.  The FASTA is replicated (1 GB of 288 GB HBM for BASELINE configs[3]); only the walk over it
+# is partitioned.
+
+def vcf_byte_range(vcf, rank, world):
+    """Byte range [lo, hi) of rank's share of the file, cut at line starts (same rule on every rank)."""
+    n = len(vcf)
+
+    def cut(k):
+        if k <= 0:
+            return 0
+        if k >= world:
+            return n
+        g = n * k // world
+        if g == 0:
+            return 0
+        nl = vcf.find(b"\n", g - 1)          # a line starts right behind the first newline at or after g-1
+        return n if nl < 0 else nl + 1
+    return cut(rank), cut(rank + 1)
+
+
+def plan_vcf_cuts(pos, reflen, order, world):
+    """Sorted-record index cuts c[0..world] (c[r] is a group start) + sorted starts; identical on every rank.
+
+    pos / reflen: numpy uint64 in file order; order: permutation of the reference's sort."""
+    import numpy as np
+    n = len(pos)
+    cuts = [0] * (world + 1)
+    cuts[world] = n
+    if n == 0:
+        return cuts, np.zeros(0, dtype=np.uint64), False
+    with np.errstate(over="ignore"):
+        start = pos[order] - np.uint64(1)                     # wraps for POS 0 like the reference's size_t
+        end = start + reflen[order]
+    wraps = bool(np.any(start == np.uint64(0xFFFFFFFFFFFFFFFF)) or np.any(end < start))
+    if wraps or world == 1:
+        for r in range(1, world):
+            cuts[r] = n
+        return cuts, start, wraps
+    prefmax = np.maximum.accumulate(end)
+    flag = np.ones(n, dtype=bool)
+    flag[1:] = start[1:] >= prefmax[:-1]                      # a record opens a group iff start >= every earlier end (:510)
+    gstarts = np.flatnonzero(flag)
+    for r in range(1, world):
+        target = n * r // world
+        k = int(np.searchsorted(gstarts, target, side="left"))
+        cuts[r] = int(gstarts[k]) if k < len(gstarts) else n
+        if cuts[r] < cuts[r - 1]:
+            cuts[r] = cuts[r - 1]
+    return cuts, start, wraps
+
+
+def _line_runs(gidx, k0, base, off, length, vcf, lo):
+    """Records gidx (global file indices owned by this rank, in sorted order, first one at sorted index k0)
+    -> [(sorted index of the first record, text)], maximal runs of lines adjacent in the file as one slice."""
+    import numpy as np
+    if len(gidx) == 0:
+        return []
+    loc = (gidx - base).astype(np.int64)
+    o, ln = off[loc].astype(np.int64), length[loc].astype(np.int64)
+    brk = np.flatnonzero((np.diff(loc) != 1) | (o[:-1] + ln[:-1] + 1 != o[1:])) + 1
+    firsts = np.concatenate(([0], brk))
+    lasts = np.concatenate((brk, [len(loc)])) - 1
+    return [(k0 + int(a), bytes(vcf[lo + int(o[a]):lo + int(o[b] + ln[b])])) for a, b in zip(firsts, lasts)]
+
+
+class VcfSharder:
+    """Runs the position-range partition for one rank.  `dist` is torch.distributed (nccl = RCCL on the GPU
+    box, gloo in the CPU tests); only all_gather_object is used.  The three callables are the C ABI on the
+    GPU (gpu_vcf_sharder) and the oracle in the CPU tests."""
+
+    def __init__(self, rank, world, dist, index_fn, sort_fn, range_fn):
+        self.rank, self.world, self.dist = rank, world, dist
+        self.index_fn = index_fn            # bytes -> (pos, reflen, line_off, line_len, counters)
+        self.sort_fn = sort_fn              # uint64[n] -> uint32[n]
+        self.range_fn = range_fn            # (lines, fasta, cur0, next_start|None) -> (eds, seds, counters)
+        self.last = None
+
+    def run(self, vcf, fasta):
+        import numpy as np
+        rank, world = self.rank, self.world
+        lo, hi = vcf_byte_range(vcf, rank, world)
+        pos, reflen, off, length, counters = self.index_fn(vcf[lo:hi])
+        gathered = [None] * world
+        self.dist.all_gather_object(gathered, (pos, reflen, counters))
+        base = np.concatenate(([0], np.cumsum([len(g[0]) for g in gathered]))).astype(np.int64)
+        gpos = np.concatenate([g[0] for g in gathered]).astype(np.uint64)
+        greflen = np.concatenate([g[1] for g in gathered]).astype(np.uint64)
+        order = self.sort_fn(gpos).astype(np.int64)
+        cuts, start, wraps = plan_vcf_cuts(gpos, greflen, order, world)
+        # lines of mine that another rank's range needs, and the runs I keep
+        outgoing = {}
+        pieces = []
+        for d in range(world):
+            g = order[cuts[d]:cuts[d + 1]]
+            sel = np.flatnonzero((g >= base[rank]) & (g < base[rank + 1]))
+            if len(sel) == 0:
+                continue
+            # runs must also be runs of the *sorted* order: split where the sorted index jumps
+            jumps = np.flatnonzero(np.diff(sel) != 1) + 1
+            runs = []
+            for a, b in zip(np.concatenate(([0], jumps)), np.concatenate((jumps, [len(sel)]))):
+                runs += _line_runs(g[sel[a:b]], cuts[d] + int(sel[a]), base[rank], off, length, vcf, lo)
+            if d == rank:
+                pieces += runs
+            else:
+                outgoing[d] = runs
+        everything = [None] * world
+        self.dist.all_gather_object(everything, outgoing)
+        for r in range(world):
+            if r != rank and rank in everything[r]:
+                pieces += everything[r][rank]
+        pieces.sort(key=lambda p: p[0])
+        lines = b"\n".join(p[1] for p in pieces)
+        nonempty = [r for r in range(world) if cuts[r] < cuts[r + 1]]
+        n_mine = cuts[rank + 1] - cuts[rank]
+        eds = seds = b""
+        groups = 0
+        err = None
+        runs_here = n_mine > 0 or (not nonempty and rank == 0)      # an empty VCF is rank 0's: the bare reference
+        if runs_here:
+            first = not nonempty or rank == nonempty[0]
+            later = [r for r in nonempty if r > rank]
+            cur0 = 0 if first else int(start[cuts[rank]])
+            next_start = int(start[cuts[later[0]]]) if later else None
+            try:
+                eds, seds, st = self.range_fn(lines, fasta, cur0, next_start)
+                groups = st["variant_groups"]
+            except Exception as ex:                                # noqa: BLE001 — re-raised on every rank below
+                err = ex
+        sizes = [None] * world
+        self.dist.all_gather_object(sizes, (len(eds), len(seds), groups, None if err is None else (type(err).__name__, str(err), getattr(err, "code", None))))
+        failed = [s[3] for s in sizes if s[3] is not None]
+        if failed:
+            if err is not None:
+                raise err
+            raise RuntimeError("VCF range transform failed on another rank: %s: %s" % (failed[0][0], failed[0][1]))
+        stats = {k: sum(g[2][k] for g in gathered) for k in
+                 ("total_variants", "processed_variants", "skipped_malformed", "skipped_unsupported_sv")}
+        stats["variant_groups"] = sum(s[2] for s in sizes)
+        self.last = {
+            "eds": eds, "seds": seds, "stats": stats, "cuts": cuts, "records": n_mine, "wraps": wraps,
+            "moved_lines_bytes": sum(len(t) for runs in outgoing.values() for _, t in runs),
+            "eds_offset": sum(s[0] for s in sizes[:rank]), "seds_offset": sum(s[1] for s in sizes[:rank]),
+            "eds_total": sum(s[0] for s in sizes), "seds_total": sum(s[1] for s in sizes),
+        }
+        return self.last
+
+
+def gpu_vcf_sharder(ctx, rank, world, dist):
+    """VcfSharder wired to the C ABI of this rank's GPU context."""
+    return VcfSharder(rank, world, dist, ctx.vcf_index, ctx.vcf_sort_order,
+                      lambda lines, fasta, cur0, nxt: ctx.vcf_transform_range(lines, fasta, cur0, nxt))

@@ -78,6 +78,29 @@ int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size,
                        const uint8_t* fasta, size_t fasta_size, uint32_t context_len,
                        edsx_buf* eds, edsx_buf* seds, edsx_vcf_stats* stats);
 
+/* ---- multi-GPU VCF: partition by reference position ----
+ * Groups of overlapping records (vcf_transforms.cpp:482-534) never span a cut placed at a group start, so
+ * every GPU walks its own position range and the pieces concatenate to the reference's text with no repair.
+ * What has to be global is the order of the records: the reference sorts the whole array with an unstable
+ * std::sort (:715-718), so every rank indexes its byte range of the file, the (POS, REF length) arrays are
+ * all-gathered, every rank derives the same order and cuts, and record lines that fall into another rank's
+ * position range are exchanged (edsparser_amd/multigpu.py, VcfSharder). */
+
+/* Index pass over VCF text: POS and REF length (uint64 each) and the line span (offset, length; uint64 each)
+ * of every record the transform would accept, in file order; counters as edsx_vcf_transform (variant_groups
+ * stays 0).  Genotypes are not parsed. */
+int edsx_vcf_index(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, edsx_buf* pos, edsx_buf* reflen,
+                   edsx_buf* line_off, edsx_buf* line_len, edsx_vcf_stats* stats);
+/* order_out[k] = index (into pos) of the k-th record after the reference's std::sort of n records. */
+int edsx_vcf_sort_order(const uint64_t* pos, size_t n, uint32_t* order_out);
+/* edsx_vcf_transform (context_len 0) of one position range: `vcf` holds the range's record lines already in
+ * their final order; the walk starts at reference position cur0 (pass the start of the range's first group
+ * for every range but the first, 0 for the first) and the closing common text stops at next_start (0-based
+ * start of the next range's first group; UINT64_MAX for the last range: flush to the end of the reference). */
+int edsx_vcf_transform_range(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, const uint8_t* fasta,
+                             size_t fasta_size, uint64_t cur0, uint64_t next_start, edsx_buf* eds,
+                             edsx_buf* seds, edsx_vcf_stats* stats);
+
 /* ---- device-resident MSA path (inputs/outputs stay in HBM) ---- */
 
 /* Phase 1: index rows, scan columns, build the segment table and size the outputs.

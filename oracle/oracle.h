@@ -56,6 +56,15 @@ int oracle_vcf(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fa
                uint32_t l, char** eds, size_t* eds_n, char** seds, size_t* seds_n,
                oracle_vcf_stats* stats, char* err, size_t errcap);
 
+/* Position-range partition of the VCF path (multi-GPU tests, world_size-2 gloo): one range with its records
+ * already in final order; index pass; the permutation of the reference's std::sort (:715-718). */
+int oracle_vcf_range(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n,
+                     uint64_t cur0, uint64_t next_start, char** eds, size_t* eds_n, char** seds, size_t* seds_n,
+                     oracle_vcf_stats* stats, char* err, size_t errcap);
+int oracle_vcf_index(const uint8_t* vcf, size_t vcf_n, uint64_t* pos_out, uint64_t* reflen_out,
+                     uint64_t* off_out, uint64_t* len_out, size_t cap, size_t* n_out, oracle_vcf_stats* stats);
+void oracle_vcf_sort_order(const uint64_t* pos, size_t n, uint32_t* order_out);
+
 void oracle_free(void* p);
 
 #ifdef __cplusplus

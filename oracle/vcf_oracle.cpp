@@ -230,9 +230,13 @@ std::vector<Group> group_variants(const std::vector<Variant>& vars, const Fasta&
     return groups;
 }
 
-void generate(const Fasta& fa, const std::vector<Group>& groups, std::string& eds, std::string& seds)   // :554-668
+// cur0 / next_start: one position range of a partitioned run (multi-GPU tests): the walk starts at cur0 and the
+// closing common text is what the reference flushes in front of the next range's first group (:570-578);
+// next_start == SIZE_MAX is the whole-file behaviour (:658-665)
+void generate(const Fasta& fa, const std::vector<Group>& groups, std::string& eds, std::string& seds,
+              size_t cur0 = 0, size_t next_start = SIZE_MAX)   // :554-668
 {
-    size_t cur = 0;
+    size_t cur = cur0;
     for (const Group& g : groups) {
         if (g.start_pos > cur) {
             std::string r = read_region(fa, cur, g.start_pos - cur);
@@ -263,6 +267,13 @@ void generate(const Fasta& fa, const std::vector<Group>& groups, std::string& ed
             seds += '}';
         }
         cur = g.end_pos;
+    }
+    if (next_start != SIZE_MAX) {
+        if (next_start > cur) {
+            std::string r = read_region(fa, cur, next_start - cur);
+            if (!r.empty()) { eds += '{'; eds += r; eds += '}'; seds += "{0}"; }
+        }
+        return;
     }
     if (cur < fa.seq_size) {                                 // :658-665
         std::string r = read_region(fa, cur, fa.seq_size - cur);
@@ -323,4 +334,71 @@ extern "C" int oracle_vcf(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta
         if (err && errcap) { strncpy(err, ex.what(), errcap - 1); err[errcap - 1] = 0; }
         return 2;
     }
+}
+
+/* One position range of a partitioned run: records already in final order (no sort). */
+extern "C" int oracle_vcf_range(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n,
+                                uint64_t cur0, uint64_t next_start, char** eds, size_t* eds_n, char** seds, size_t* seds_n,
+                                oracle_vcf_stats* stats, char* err, size_t errcap)
+{
+    try {
+        Fasta fa = parse_fasta(fasta, fasta_n);
+        std::vector<Variant> vars;
+        size_t n_samples = 0, pos = 0;
+        std::string line;
+        oracle_vcf_stats st{};
+        while (next_line(vcf, vcf_n, pos, line)) {
+            Skip skip; Variant v;
+            bool ok = parse_line(line, n_samples, skip, v);
+            if (skip == Skip::NONE) { st.total_variants++; st.processed_variants++; }
+            else if (skip == Skip::MALFORMED) { st.total_variants++; st.skipped_malformed++; }
+            else if (skip == Skip::UNSUPPORTED_SV) { st.total_variants++; st.skipped_unsupported_sv++; }
+            if (ok) vars.push_back(std::move(v));
+        }
+        std::vector<Group> groups = group_variants(vars, fa);
+        std::string e, s;
+        generate(fa, groups, e, s, cur0, next_start == UINT64_MAX ? SIZE_MAX : (size_t)next_start);
+        st.variant_groups = groups.size();
+        if (stats) *stats = st;
+        *eds = dup_out(e, eds_n);
+        *seds = dup_out(s, seds_n);
+        return 0;
+    } catch (const std::exception& ex) {
+        if (err && errcap) { strncpy(err, ex.what(), errcap - 1); err[errcap - 1] = 0; }
+        return 2;
+    }
+}
+
+/* Index pass (positions, REF lengths, line spans of the accepted records) and the std::sort permutation. */
+extern "C" int oracle_vcf_index(const uint8_t* vcf, size_t vcf_n, uint64_t* pos_out, uint64_t* reflen_out,
+                                uint64_t* off_out, uint64_t* len_out, size_t cap, size_t* n_out, oracle_vcf_stats* stats)
+{
+    size_t n_samples = 0, pos = 0, n = 0;
+    std::string line;
+    oracle_vcf_stats st{};
+    while (true) {
+        const size_t lo = pos;
+        if (!next_line(vcf, vcf_n, pos, line)) break;
+        Skip skip; Variant v;
+        bool ok = false;
+        try { ok = parse_line(line, n_samples, skip, v); } catch (...) { return 2; }
+        if (skip == Skip::NONE) { st.total_variants++; st.processed_variants++; }
+        else if (skip == Skip::MALFORMED) { st.total_variants++; st.skipped_malformed++; }
+        else if (skip == Skip::UNSUPPORTED_SV) { st.total_variants++; st.skipped_unsupported_sv++; }
+        if (ok) {
+            if (n < cap) { pos_out[n] = v.pos; reflen_out[n] = v.ref.size(); off_out[n] = lo; len_out[n] = line.size(); }
+            n++;
+        }
+    }
+    *n_out = n;
+    if (stats) *stats = st;
+    return n <= cap ? 0 : 1;
+}
+
+extern "C" void oracle_vcf_sort_order(const uint64_t* pos, size_t n, uint32_t* order_out)
+{
+    std::vector<std::pair<uint64_t, uint32_t>> o(n);
+    for (size_t i = 0; i < n; i++) o[i] = {pos[i], (uint32_t)i};
+    std::sort(o.begin(), o.end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; });
+    for (size_t i = 0; i < n; i++) order_out[i] = o[i].second;
 }

@@ -114,6 +114,42 @@ def vcf(vcf_bytes, fasta_bytes, l=0):
     return e, s, st.as_dict()
 
 
+def vcf_range(vcf_lines, fasta_bytes, cur0=0, next_start=None):
+    lib = _load()
+    v, vn = _buf(vcf_lines)
+    f, fn = _buf(fasta_bytes)
+    st = VcfStats()
+    nxt = 0xFFFFFFFFFFFFFFFF if next_start is None else int(next_start)
+    e, s = _call(lib.oracle_vcf_range, lib.oracle_free,
+                 [v, ctypes.c_size_t(vn), f, ctypes.c_size_t(fn), ctypes.c_uint64(int(cur0)), ctypes.c_uint64(nxt)],
+                 extra=(ctypes.byref(st),))
+    return e, s, st.as_dict()
+
+
+def vcf_index(vcf_bytes):
+    import numpy as np
+    lib = _load()
+    v, vn = _buf(vcf_bytes)
+    cap = bytes(vcf_bytes).count(b"\n") + 1
+    arrs = [np.zeros(cap, dtype=np.uint64) for _ in range(4)]
+    n = ctypes.c_size_t()
+    st = VcfStats()
+    rc = lib.oracle_vcf_index(v, ctypes.c_size_t(vn), *[ctypes.c_void_p(a.ctypes.data) for a in arrs],
+                              ctypes.c_size_t(cap), ctypes.byref(n), ctypes.byref(st))
+    if rc != 0:
+        raise OracleError(rc, "oracle_vcf_index failed")
+    return (*[a[:n.value].copy() for a in arrs], st.as_dict())
+
+
+def vcf_sort_order(pos):
+    import numpy as np
+    lib = _load()
+    pos = np.ascontiguousarray(pos, dtype=np.uint64)
+    out = np.empty(len(pos), dtype=np.uint32)
+    lib.oracle_vcf_sort_order(ctypes.c_void_p(pos.ctypes.data), ctypes.c_size_t(len(pos)), ctypes.c_void_p(out.ctypes.data))
+    return out
+
+
 # ---- the real reference (build container only; merge + VCF paths) ----
 
 def ref_merge(eds, seds=None, l=1, compact=True, threads=1):
