@@ -68,6 +68,9 @@ def load_library():
                                     ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, P(_Buf), P(_Buf)]
     lib.edsx_vcf_transform.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                        ctypes.c_size_t, ctypes.c_uint32, P(_Buf), P(_Buf), P(VcfStats)]
+    lib.edsx_leds_merge_range.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                          ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          P(_Buf), P(_Buf), P(ctypes.c_int), P(ctypes.c_int)]
     lib.edsx_vcf_index.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, P(_Buf), P(_Buf), P(_Buf), P(_Buf),
                                    P(VcfStats)]
     lib.edsx_vcf_sort_order.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
@@ -150,6 +153,19 @@ class Context:
         self._check(self._lib.edsx_vcf_transform(self._h, vcf, len(vcf), fasta, len(fasta), context_len,
                                                  ctypes.byref(e), ctypes.byref(s), ctypes.byref(st)))
         return self._take(e), self._take(s), {n: int(getattr(st, n)) for n, _ in VcfStats._fields_}
+
+    # ---- symbol-range partition of the merge (multi-GPU, see multigpu.MergeSharder)
+    def leds_merge_range(self, eds, seds=None, context_len=1, compact=True, head_sentinel=False, tail_sentinel=False):
+        """-> (leds, seds_out, head_intact, tail_intact)"""
+        o, so = _Buf(), _Buf()
+        hi, ti = ctypes.c_int(), ctypes.c_int()
+        eds = bytes(eds)
+        sb = bytes(seds) if seds is not None else None
+        self._check(self._lib.edsx_leds_merge_range(self._h, eds, len(eds), sb, len(sb) if sb is not None else 0,
+                                                    context_len, 1 if compact else 0, 1 if head_sentinel else 0,
+                                                    1 if tail_sentinel else 0, ctypes.byref(o), ctypes.byref(so),
+                                                    ctypes.byref(hi), ctypes.byref(ti)))
+        return self._take(o), self._take(so), bool(hi.value), bool(ti.value)
 
     # ---- position-range partition of the VCF path (multi-GPU, see multigpu.VcfSharder)
     def vcf_index(self, vcf):

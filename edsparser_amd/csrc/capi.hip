@@ -181,6 +181,30 @@ int edsx_leds_merge(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const ui
     });
 }
 
+int edsx_leds_merge_range(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const uint8_t* seds, size_t seds_size,
+                          uint32_t context_len, int compact, int head_sentinel, int tail_sentinel, edsx_buf* leds,
+                          edsx_buf* seds_out, int* head_intact, int* tail_intact)
+{
+    if (leds) { leds->data = nullptr; leds->size = 0; }
+    if (seds_out) { seds_out->data = nullptr; seds_out->size = 0; }
+    if (head_intact) *head_intact = 0;
+    if (tail_intact) *tail_intact = 0;
+    return guarded(ctx, [&] {
+        if (!leds || !seds_out || !head_intact || !tail_intact || (!eds && eds_size)) throw ParamError("null argument");
+        std::string out, sout;
+        static const uint8_t none = 0;
+        MergeShard sh;
+        sh.head_sentinel = head_sentinel != 0; sh.tail_sentinel = tail_sentinel != 0;
+        ctx->merge.run(eds ? eds : &none, eds_size, seds, seds_size, context_len, compact != 0, out, sout, nullptr, &sh);
+        *head_intact = sh.head_intact ? 1 : 0;
+        *tail_intact = sh.tail_intact ? 1 : 0;
+        take(leds, out.size());
+        std::memcpy(leds->data, out.data(), out.size());
+        take(seds_out, sout.size());
+        std::memcpy(seds_out->data, sout.data(), sout.size());
+    });
+}
+
 int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, const uint8_t* fasta, size_t fasta_size,
                        uint32_t context_len, edsx_buf* eds, edsx_buf* seds, edsx_vcf_stats* stats)
 {

@@ -407,7 +407,7 @@ void grow_keep(DevBuf& b, size_t used, size_t need, hipStream_t st)
 } // namespace
 
 void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l, bool compact,
-                        std::string& out, std::string& seds_out, hipStream_t st)
+                        std::string& out, std::string& seds_out, hipStream_t st, MergeShard* shard)
 {
     if (l == 0) throw ParamError("context_length must be > 0 for l-EDS transformation");   // :322-324
     const bool linear = seds != nullptr;
@@ -508,6 +508,13 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
         return;
     }
     if (m >= 0xfffffff0ull) throw FormatError("EDS has too many strings for this build");
+    if (shard) {
+        shard->head_intact = shard->tail_intact = true;
+        if ((shard->head_sentinel && sym_first[1] - sym_first[0] != 1) ||
+            (shard->tail_sentinel && sym_first[n0] - sym_first[n0 - 1] != 1) ||
+            ((shard->head_sentinel && shard->tail_sentinel) && n0 < 3))
+            throw ParamError("a sentinel of a symbol range must be a single-string symbol of its own");
+    }
 
     // ---- upload
     d_chars_.ensure(chars.size() + 16);
@@ -587,6 +594,19 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     }
     if (iteration >= MAX_ITERATIONS) throw FormatError("Maximum iterations reached without convergence");
 
+    // ---- symbol range of a partitioned merge: did the sentinels stay out of every merge?  Merged symbols get
+    // fresh pool entries (>= m), an untouched sentinel still points at its leaf.
+    if (shard && (shard->head_sentinel || shard->tail_sentinel)) {
+        u64 h[4] = {0, 0, 0, 0};
+        EDSX_HIP(hipMemcpyAsync(h + 0, size_[cur].as<u64>(), 8, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipMemcpyAsync(h + 1, ent_off_[cur].as<u64>(), 8, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipMemcpyAsync(h + 2, size_[cur].as<u64>() + (n - 1), 8, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipMemcpyAsync(h + 3, ent_off_[cur].as<u64>() + (n - 1), 8, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        if (shard->head_sentinel) shard->head_intact = h[0] == 1 && h[1] == 0 && n >= 2;
+        if (shard->tail_sentinel) shard->tail_intact = h[2] == 1 && h[3] == m - 1 && n >= 2;
+    }
+
     // ---- final text
     SymArrays sf{size_[cur].as<u64>(), ent_off_[cur].as<u64>(), len1_[cur].as<u64>()};
     Pool pool{left_.as<u32>(), right_.as<u32>(), elen_.as<u32>(), bits_.as<u64>(), W};
@@ -626,6 +646,14 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     if (hctl[4]) throw FormatError("l-EDS merge nesting deeper than this build supports");
     out[E] = '\n';                                           // eds.cpp:630
     if (linear) seds_out[Q] = '\n';                          // eds.cpp:658
+    if (shard && shard->tail_sentinel) {                     // not the last range: the text goes on
+        out.pop_back();
+        if (linear) seds_out.pop_back();
+    }
+    if (shard && shard->head_sentinel && shard->head_intact) {   // the left neighbour prints the shared sentinel
+        out.erase(0, (size_t)(str_off[1] - str_off[0]) + (compact ? 0 : 2));
+        if (linear) seds_out.erase(0, seds_out.find('}') + 1);
+    }
 }
 
 } // namespace edsx

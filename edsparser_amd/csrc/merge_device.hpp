@@ -7,11 +7,23 @@
 
 namespace edsx {
 
+// One symbol range of a partitioned merge.  Neighbouring ranges share a sentinel: a single-string
+// symbol of at least l characters between two degenerate symbols.  No pair with the sentinel is mergeable while its
+// neighbours stay degenerate (eds_transforms.cpp:75-97), so runs of mergeable pairs never cross it and both sides
+// evolve exactly as they do inside the whole EDS.  A range reports whether its sentinels came through unmerged
+// (a LINEAR product can collapse a neighbour to one short string, which then pulls the sentinel in); the caller
+// falls back to the unpartitioned merge when one did not.  The left range prints the sentinel, the right one drops it;
+// only the last range ends in '\n'.
+struct MergeShard {
+    bool head_sentinel = false, tail_sentinel = false;   // in
+    bool head_intact = true, tail_intact = true;         // out
+};
+
 class MergePipeline {
 public:
     // eds/seds are host buffers (seds == nullptr => CARTESIAN); outputs end in '\n' like EDS::save.
     void run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l, bool compact,
-             std::string& out, std::string& seds_out, hipStream_t st);
+             std::string& out, std::string& seds_out, hipStream_t st, MergeShard* shard = nullptr);
 
 private:
     DevBuf d_chars_, d_str_off_, left_, right_, elen_, bits_, size_[2], ent_off_[2], len1_[2], a_, b_, c_, d_, e_,

@@ -376,3 +376,225 @@ def gpu_vcf_sharder(ctx, rank, world, dist):
     """VcfSharder wired to the C ABI of this rank's GPU context."""
     return VcfSharder(rank, world, dist, ctx.vcf_index, ctx.vcf_sort_order,
                       lambda lines, fasta, cur0, nxt: ctx.vcf_transform_range(lines, fasta, cur0, nxt))
+
+
+# ======================================================================================================
+# EDS -> l-EDS merge over several GPUs: partition by symbol range (SURVEY §8(e), merge row)
+# ======================================================================================================
+#
+# A pair (i, i+1) is merged when one of the two is a short single string (shorter than l, not the first / last
+# symbol) or both are degenerate (eds_transforms.cpp:75-97); inside a run of consecutive mergeable pairs the pairs at
+# even offsets are taken (:63-66).  A *sentinel* — a single-string symbol of at least l characters whose two
+# neighbours are degenerate — is in no mergeable pair, so no run crosses it and the two sides evolve exactly as
+# inside the whole EDS, round for round.  Neighbouring ranks share the sentinel symbol (last symbol of the left
+# range, first of the right range); the left one prints it.  The only way a sentinel can be drawn into a merge later
+# is a LINEAR product collapsing its degenerate neighbour to one short string; every range reports whether its
+# sentinels stayed untouched (edsx_leds_merge_range) and if one did not — or a range fails — rank 0 runs the
+# unpartitioned merge, which also yields the reference's error text with whole-file positions.
+#
+# Exchange steps (all_gather_object of a few integers each):
+#   1. every rank scans its byte range of .eds / .seds: string starts, '{' of .seds, and the first sentinel at or after
+#      the start of its range (with the number of strings in front of it inside the range),
+#   2. the ranks that hold the sentinels' source sets in .seds locate them (set index = strings in front),
+#   3. piece sizes + sentinel flags.
+# Text with whitespace inside (other than at the end), commas outside braces or unbalanced braces is not
+# partitioned (rank 0 takes it whole): the tools never write such files, and the tokeniser's exact error texts
+# come from the whole-file path.
+
+def _np_bytes(buf, lo, hi):
+    import numpy as np
+    return np.frombuffer(buf, dtype=np.uint8, count=hi - lo, offset=lo)
+
+
+def _text_end(buf):
+    """Length without trailing whitespace."""
+    n = len(buf)
+    while n and buf[n - 1:n].isspace():
+        n -= 1
+    return n
+
+
+def eds_scan_range(eds, lo, hi, l, end, margin=1 << 16):
+    """Scan bytes [lo, hi) of .eds text (hi <= end = text length without trailing whitespace).
+
+    -> dict(ok, strings, cut) with cut = None or (sym_start, sym_end, strings_in_range_before_it): the first sentinel
+    whose preceding '}' lies in [lo, hi)."""
+    import numpy as np
+    res = {"ok": True, "strings": 0, "cut": None}
+    if hi <= lo:
+        return res
+    a = _np_bytes(eds, lo, hi)
+    if np.any((a == 32) | ((a >= 9) & (a <= 13))):
+        res["ok"] = False
+        return res
+    is_o, is_c, is_comma = a == 0x7B, a == 0x7D, a == 0x2C
+    inside0 = 1 if eds.rfind(b"{", 0, lo) > eds.rfind(b"}", 0, lo) else 0
+    delta = is_o.astype(np.int8) - is_c.astype(np.int8)
+    depth_after = inside0 + np.cumsum(delta, dtype=np.int64)
+    depth_before = depth_after - delta
+    if depth_after.min(initial=0) < 0 or depth_after.max(initial=0) > 1 or np.any(is_comma & (depth_before == 0)) \
+            or np.any(is_o & (depth_before == 1)):
+        res["ok"] = False
+        return res
+    prev = np.empty_like(a)
+    prev[1:] = a[:-1]
+    prev[0] = eds[lo - 1] if lo > 0 else 0x7D
+    starts = is_o | is_comma | ((depth_before == 0) & ~is_o & ~is_c & (prev == 0x7D))
+    cs = np.concatenate(([0], np.cumsum(starts, dtype=np.int64)))
+    res["strings"] = int(cs[-1])
+    if lo == 0:
+        return res                                               # rank 0's range starts the text: no cut of its own
+    # ---- first sentinel: brace sequence of a window that reaches one group back and `margin` bytes ahead
+    w0 = eds.rfind(b"{", 0, lo)
+    w0 = lo if w0 < 0 else w0
+    w1 = min(end, hi + margin + 4 * l)
+    w = _np_bytes(eds, w0, w1)
+    if np.any((w == 32) | ((w >= 9) & (w <= 13))):
+        return res                                               # whitespace ahead: some rank reports it
+    bmask = (w == 0x7B) | (w == 0x7D)
+    bp = np.flatnonzero(bmask).astype(np.int64)
+    bt = w[bp] == 0x7B                                           # True = '{'
+    cc = np.concatenate(([0], np.cumsum(w == 0x2C, dtype=np.int64)))
+    nb = len(bp)
+    if nb < 4:
+        return res
+
+    def commas(x, y):                                            # commas strictly between window positions x < y
+        return cc[y] - cc[x + 1]
+
+    k = np.arange(1, nb - 1)                                     # bp[k] is the '}' in front of the sentinel
+    base = (~bt[k]) & bt[k - 1] & (commas(bp[k - 1], bp[k]) > 0) & (bp[k] + w0 >= lo) & (bp[k] + w0 < hi) & bt[k + 1]
+    need = max(int(l), 1)
+    # COMPACT: } p {x,y}
+    k2 = np.minimum(k + 2, nb - 1)
+    compact = base & (bp[k + 1] - bp[k] - 1 >= need) & (commas(bp[k], bp[k + 1]) == 0) & (k + 2 < nb) & (~bt[k2]) & (commas(bp[k + 1], bp[k2]) > 0)
+    # FULL: }{p}{x,y}
+    k3, k4 = np.minimum(k + 3, nb - 1), np.minimum(k + 4, nb - 1)
+    full = base & (bp[k + 1] == bp[k] + 1) & (k + 4 < nb) & (~bt[k2]) & (bp[k2] - bp[k + 1] - 1 >= need) & \
+        (commas(bp[k + 1], bp[k2]) == 0) & bt[k3] & (bp[k3] == bp[k2] + 1) & (~bt[k4]) & (commas(bp[k3], bp[k4]) > 0)
+    hit = np.flatnonzero(compact | full)
+    if len(hit) == 0:
+        return res
+    j = int(hit[0])
+    kk = int(k[j])
+    if compact[j]:
+        s, e = int(bp[kk]) + 1 + w0, int(bp[kk + 1]) + w0
+    else:
+        s, e = int(bp[kk + 1]) + w0, int(bp[kk + 2]) + 1 + w0
+    res["cut"] = (s, e, int(cs[s - lo]))
+    return res
+
+
+def seds_scan_range(seds, lo, hi):
+    """-> (ok, number of '{' in [lo, hi))"""
+    import numpy as np
+    if hi <= lo:
+        return True, 0
+    a = _np_bytes(seds, lo, hi)
+    if np.any((a == 32) | ((a >= 9) & (a <= 13))):
+        return False, 0
+    return True, int(np.count_nonzero(a == 0x7B))
+
+
+class MergeSharder:
+    """Runs the symbol-range partition of the merge for one rank.  range_fn / whole_fn are the C ABI on the GPU
+    (gpu_merge_sharder) and the oracle in the CPU tests."""
+
+    def __init__(self, rank, world, dist, range_fn, whole_fn):
+        self.rank, self.world, self.dist = rank, world, dist
+        self.range_fn = range_fn    # (eds, seds|None, l, compact, head, tail) -> (leds, seds_out, head_intact, tail_intact)
+        self.whole_fn = whole_fn    # (eds, seds|None, l, compact) -> (leds, seds_out)
+        self.last = None
+
+    def _whole_on_rank0(self, eds, seds, l, compact, why):
+        out, sout, err = b"", b"", None
+        if self.rank == 0:
+            try:
+                out, sout = self.whole_fn(eds, seds, l, compact)
+            except Exception as ex:  # noqa: BLE001 — raised on every rank below
+                err = ex
+        sizes = [None] * self.world
+        self.dist.all_gather_object(sizes, (len(out), len(sout), None if err is None else (type(err).__name__, str(err))))
+        if sizes[0][2] is not None:
+            if err is not None:
+                raise err
+            raise RuntimeError("merge failed on rank 0: %s: %s" % sizes[0][2])
+        self.last = {"leds": out, "seds": sout, "partitioned": False, "why": why, "ranges": 1,
+                     "leds_offset": 0 if self.rank == 0 else sizes[0][0], "seds_offset": 0 if self.rank == 0 else sizes[0][1],
+                     "leds_total": sizes[0][0], "seds_total": sizes[0][1]}
+        return self.last
+
+    def run(self, eds, seds, l, compact=True):
+        import numpy as np
+        rank, world = self.rank, self.world
+        linear = seds is not None
+        if world == 1 or l == 0:
+            return self._whole_on_rank0(eds, seds, l, compact, "single rank")
+        end = _text_end(eds)
+        lo, hi = end * rank // world, end * (rank + 1) // world
+        scan = eds_scan_range(eds, lo, hi, l, end)
+        send = _text_end(seds) if linear else 0
+        slo, shi = send * rank // world, send * (rank + 1) // world
+        sok, sbraces = seds_scan_range(seds, slo, shi) if linear else (True, 0)
+        g1 = [None] * world
+        self.dist.all_gather_object(g1, (scan["ok"] and sok, scan["strings"], scan["cut"], sbraces))
+        if not all(g[0] for g in g1):
+            return self._whole_on_rank0(eds, seds, l, compact, "text not partitionable")
+        str_base = np.concatenate(([0], np.cumsum([g[1] for g in g1])))
+        cut_ranks = [r for r in range(1, world) if g1[r][2] is not None]
+        if not cut_ranks:
+            return self._whole_on_rank0(eds, seds, l, compact, "no sentinel found")
+        sent = {r: (g1[r][2][0], g1[r][2][1], int(str_base[r]) + g1[r][2][2]) for r in cut_ranks}   # start, end, string index
+        # ---- .seds: the set of string M starts at the M-th '{'
+        located = {}
+        if linear:
+            br_base = np.concatenate(([0], np.cumsum([g[3] for g in g1])))
+            if br_base[-1] != str_base[-1]:
+                return self._whole_on_rank0(eds, seds, l, compact, "source count differs from the cardinality")
+            mine = [r for r in cut_ranks if br_base[rank] <= sent[r][2] < br_base[rank + 1]]
+            if mine:
+                pos = np.flatnonzero(_np_bytes(seds, slo, shi) == 0x7B)
+                for r in mine:
+                    p0 = int(pos[sent[r][2] - int(br_base[rank])]) + slo
+                    located[r] = (p0, seds.find(b"}", p0) + 1)
+            g2 = [None] * world
+            self.dist.all_gather_object(g2, located)
+            located = {}
+            for g in g2:
+                located.update(g)
+            if any(r not in located or located[r][1] <= 0 for r in cut_ranks):
+                return self._whole_on_rank0(eds, seds, l, compact, "source set of a sentinel not found")
+        # ---- my range
+        owners = [0] + cut_ranks
+        out = sout = b""
+        head_ok = tail_ok = True
+        err = None
+        if rank in owners:
+            i = owners.index(rank)
+            nxt = owners[i + 1] if i + 1 < len(owners) else None
+            e0 = 0 if rank == 0 else sent[rank][0]
+            e1 = len(eds) if nxt is None else sent[nxt][1]
+            s_slice = None
+            if linear:
+                s0 = 0 if rank == 0 else located[rank][0]
+                s1 = len(seds) if nxt is None else located[nxt][1]
+                s_slice = seds[s0:s1]
+            try:
+                out, sout, head_ok, tail_ok = self.range_fn(eds[e0:e1], s_slice, l, compact, rank != 0, nxt is not None)
+            except Exception as ex:  # noqa: BLE001 — any failure sends the whole text to rank 0 (exact error text)
+                err = ex
+        g3 = [None] * world
+        self.dist.all_gather_object(g3, (len(out), len(sout), head_ok and tail_ok and err is None))
+        if not all(g[2] for g in g3):
+            return self._whole_on_rank0(eds, seds, l, compact, "a sentinel was merged or a range failed")
+        self.last = {"leds": out, "seds": sout, "partitioned": True, "why": "", "ranges": len(owners),
+                     "leds_offset": sum(g[0] for g in g3[:rank]), "seds_offset": sum(g[1] for g in g3[:rank]),
+                     "leds_total": sum(g[0] for g in g3), "seds_total": sum(g[1] for g in g3)}
+        return self.last
+
+
+def gpu_merge_sharder(ctx, rank, world, dist):
+    """MergeSharder wired to the C ABI of this rank's GPU context."""
+    return MergeSharder(rank, world, dist,
+                        lambda e, s, l, c, h, t: ctx.leds_merge_range(e, s, l, c, h, t),
+                        lambda e, s, l, c: ctx.leds_merge(e, s, l, c))

@@ -101,6 +101,18 @@ int edsx_vcf_transform_range(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size,
                              size_t fasta_size, uint64_t cur0, uint64_t next_start, edsx_buf* eds,
                              edsx_buf* seds, edsx_vcf_stats* stats);
 
+/* ---- multi-GPU merge: partition by symbol range ----
+ * edsx_leds_merge of one symbol range of a larger EDS.  Neighbouring ranges overlap in one sentinel symbol (a single
+ * string of at least context_len characters between two degenerate symbols; edsparser_amd/multigpu.py, MergeSharder,
+ * finds them): head_sentinel / tail_sentinel say that the first / last symbol of this text is such a shared symbol.
+ * The range that has it as its tail prints it, the one that has it as its head drops it; only a range without a tail
+ * sentinel ends its outputs in '\n'.  *head_intact / *tail_intact come back 0 when the sentinel was drawn into a merge
+ * (possible only when a LINEAR product collapses its neighbour to a single short string): the partition is then
+ * invalid for this input and the caller must run edsx_leds_merge on the whole text. */
+int edsx_leds_merge_range(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const uint8_t* seds, size_t seds_size,
+                          uint32_t context_len, int compact, int head_sentinel, int tail_sentinel,
+                          edsx_buf* leds, edsx_buf* seds_out, int* head_intact, int* tail_intact);
+
 /* ---- device-resident MSA path (inputs/outputs stay in HBM) ---- */
 
 /* Phase 1: index rows, scan columns, build the segment table and size the outputs.

@@ -268,3 +268,65 @@ extern "C" int oracle_merge(const uint8_t* eds, size_t eds_n, const uint8_t* sed
         return dynamic_cast<const std::invalid_argument*>(&ex) ? 3 : 2;
     }
 }
+
+/* One symbol range of a partitioned merge (multi-GPU tests): first / last symbol may be a sentinel shared with the
+ * neighbouring range.  Intactness is tracked independently of the device code: every current symbol carries the
+ * number of original symbols it covers. */
+extern "C" int oracle_merge_range(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n,
+                                  uint32_t l, int compact, int head_sentinel, int tail_sentinel,
+                                  char** out, size_t* out_n, char** seds_out, size_t* seds_out_n,
+                                  int* head_intact, int* tail_intact, char* err, size_t errcap)
+{
+    try {
+        if (l == 0) throw std::invalid_argument("context_length must be > 0 for l-EDS transformation");
+        Eds e;
+        parse_eds(eds, eds_n, e);
+        if (seds) parse_sources(seds, seds_n, e);
+        const size_t head_len = e.sets.empty() ? 0 : e.sets[0][0].size();
+        std::vector<size_t> span(e.sets.size(), 1);
+        size_t iteration = 0;
+        while (iteration < 10000) {
+            if (is_leds(e, l)) break;
+            std::vector<size_t> pairs = select_pairs(e, l);
+            if (pairs.empty()) break;
+            e = merge_round(e, pairs);
+            std::vector<size_t> ns;
+            size_t pi = 0;
+            for (size_t pos = 0; pos < span.size(); pos++) {
+                if (pi < pairs.size() && pairs[pi] == pos) { ns.push_back(span[pos] + span[pos + 1]); pos++; pi++; }
+                else ns.push_back(span[pos]);
+            }
+            span.swap(ns);
+            iteration++;
+        }
+        if (iteration >= 10000) throw std::runtime_error("Maximum iterations reached without convergence");
+        *head_intact = !head_sentinel || (span.size() >= 2 && span.front() == 1);
+        *tail_intact = !tail_sentinel || (span.size() >= 2 && span.back() == 1);
+        std::string text, st;
+        size_t first = (head_sentinel && *head_intact) ? 1 : 0, cum = 0;
+        for (size_t i = 0; i < e.sets.size(); i++) {
+            if (i >= first) {
+                bool br = !compact || degenerate(e, i);
+                if (br) text.push_back('{');
+                for (size_t j = 0; j < e.sets[i].size(); j++) { if (j) text.push_back(','); text += e.sets[i][j]; }
+                if (br) text.push_back('}');
+                if (e.has_sources)
+                    for (size_t j = 0; j < e.sets[i].size(); j++) {
+                        st.push_back('{');
+                        bool f = true;
+                        for (int id : e.sources[cum + j]) { if (!f) st.push_back(','); st += std::to_string(id); f = false; }
+                        st.push_back('}');
+                    }
+            }
+            cum += e.sets[i].size();
+        }
+        (void)head_len;
+        if (!tail_sentinel) { text.push_back('\n'); if (e.has_sources) st.push_back('\n'); }
+        *out = dup_out(text, out_n);
+        *seds_out = dup_out(st, seds_out_n);
+        return 0;
+    } catch (const std::exception& ex) {
+        if (err && errcap) { strncpy(err, ex.what(), errcap - 1); err[errcap - 1] = 0; }
+        return dynamic_cast<const std::invalid_argument*>(&ex) ? 3 : 2;
+    }
+}

@@ -65,6 +65,12 @@ int oracle_vcf_index(const uint8_t* vcf, size_t vcf_n, uint64_t* pos_out, uint64
                      uint64_t* off_out, uint64_t* len_out, size_t cap, size_t* n_out, oracle_vcf_stats* stats);
 void oracle_vcf_sort_order(const uint64_t* pos, size_t n, uint32_t* order_out);
 
+/* Symbol-range partition of the merge (multi-GPU tests): see edsx_leds_merge_range in include/edsx.h. */
+int oracle_merge_range(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n,
+                       uint32_t l, int compact, int head_sentinel, int tail_sentinel,
+                       char** out, size_t* out_n, char** seds_out, size_t* seds_out_n,
+                       int* head_intact, int* tail_intact, char* err, size_t errcap);
+
 void oracle_free(void* p);
 
 #ifdef __cplusplus

@@ -45,3 +45,36 @@ def campaign_eds(rng):
     if rng.random() < 0.2: text = text.replace("}{", "}\n{", 3)
     seds = "".join("{" + ",".join(map(str, s)) + "}" for s in srcs) if linear else None
     return text.encode(), (seds.encode() if seds else None), l, rng.random() < 0.5, (n, p_deg, paths, maxlen, linear, case_mode, prod)
+
+
+def genrandomeds_shaped(ref_mb, v, seed, paths=4):
+    """genrandomeds-shaped .eds / .seds pair: uniform ACGT reference, floor(bp * v) single-base
+    sites with 2..4 alternatives (reference base, SNPs, insertions of 1..10 bases, deletions), 4 paths."""
+    rng = random.Random(seed)
+    L = int(ref_mb * 1e6)
+    ref = rng.choices("ACGT", k=L)
+    sites = sorted(rng.sample(range(L), int(L * v)))
+    eds, seds, cur = [], [], 0
+    for p in sites:
+        if p > cur:
+            eds.append("{" + "".join(ref[cur:p]) + "}")
+            seds.append("{0}")
+        k = rng.randint(2, 4)
+        alts = [ref[p]]
+        for _ in range(k - 1):
+            r = rng.random()
+            if r < 0.7:
+                alts.append(rng.choice([b for b in "ACGT" if b != ref[p]]))
+            elif r < 0.85:
+                alts.append(ref[p] + "".join(rng.choices("ACGT", k=rng.randint(1, 10))))
+            else:
+                alts.append("")
+        choice = [pp if pp < k else rng.randrange(k) for pp in range(paths)]
+        eds.append("{" + ",".join(alts) + "}")
+        for a in range(k):
+            seds.append("{" + ",".join(str(i + 1) for i, c in enumerate(choice) if c == a) + "}")
+        cur = p + 1
+    if cur < L:
+        eds.append("{" + "".join(ref[cur:]) + "}")
+        seds.append("{0}")
+    return "".join(eds).encode(), "".join(seds).encode()

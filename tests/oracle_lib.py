@@ -103,6 +103,19 @@ def merge(eds, seds=None, l=1, compact=True):
                         ctypes.c_int(1 if compact else 0)]))
 
 
+def merge_range(eds, seds=None, l=1, compact=True, head_sentinel=False, tail_sentinel=False):
+    """-> (leds, seds_out, head_intact, tail_intact)"""
+    lib = _load()
+    e, en = _buf(eds)
+    s, sn = _buf(seds)
+    hi, ti = ctypes.c_int(), ctypes.c_int()
+    a, b = _call(lib.oracle_merge_range, lib.oracle_free,
+                 [e, ctypes.c_size_t(en), s, ctypes.c_size_t(sn), ctypes.c_uint32(l), ctypes.c_int(1 if compact else 0),
+                  ctypes.c_int(1 if head_sentinel else 0), ctypes.c_int(1 if tail_sentinel else 0)],
+                 extra=(ctypes.byref(hi), ctypes.byref(ti)))
+    return a, b, bool(hi.value), bool(ti.value)
+
+
 def vcf(vcf_bytes, fasta_bytes, l=0):
     lib = _load()
     v, vn = _buf(vcf_bytes)
