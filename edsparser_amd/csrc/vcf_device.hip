@@ -46,11 +46,22 @@ __device__ __forceinline__ u64 fa_cpos(const VcfDev& d, u64 file_off)
     if (file_off >= d.fasta_n) return d.refc_n;
     const u64 rel = file_off - d.seq_start;
     u64 c = d.blkpre[rel >> 8];
-    for (u64 f = d.seq_start + (rel & ~255ull); f < file_off; f++) {
-        const uint8_t ch = d.fasta[f];
-        c += (ch != '\n' && ch != '\r');
+    // sequence bytes in [block start, file_off): eight bytes per (unaligned) load, line breaks counted with an exact
+    // SWAR zero-byte test; the buffer has 16 bytes of slack behind fasta_n, bytes at or past file_off are masked out
+    u64 f = d.seq_start + (rel & ~255ull);
+    u64 breaks = 0;
+    while (f < file_off) {
+        u64 w;
+        __builtin_memcpy(&w, d.fasta + f, 8);
+        const u64 left = file_off - f;
+        const u64 keep = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
+        const u64 a = w ^ 0x0a0a0a0a0a0a0a0aull, b = w ^ 0x0d0d0d0d0d0d0d0dull;
+        const u64 nza = (((a & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | a) & 0x8080808080808080ull;   // high bit = byte != '\n'
+        const u64 nzb = (((b & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | b) & 0x8080808080808080ull;
+        breaks += __builtin_popcountll(~(nza & nzb) & 0x8080808080808080ull & keep);
+        f += 8;
     }
-    return c;
+    return c + (file_off - (d.seq_start + (rel & ~255ull))) - breaks;
 }
 
 // ---- reference stream ---------------------------------------------------------------------------

@@ -93,4 +93,5 @@ def main():
               % ((len(vcf) + len(fasta)) / 1e6, t_whole, world, t, moved, same), flush=True)
 
 
-main()
+if __name__ == "__main__":
+    main()
