@@ -68,6 +68,7 @@ def load_library():
                                     ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, P(_Buf), P(_Buf)]
     lib.edsx_vcf_transform.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                        ctypes.c_size_t, ctypes.c_uint32, P(_Buf), P(_Buf), P(VcfStats)]
+    lib.edsx_leds_tokenised_on_device.argtypes = [ctypes.c_void_p]
     lib.edsx_leds_merge_range.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                           ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           P(_Buf), P(_Buf), P(ctypes.c_int), P(ctypes.c_int)]
@@ -153,6 +154,9 @@ class Context:
         self._check(self._lib.edsx_vcf_transform(self._h, vcf, len(vcf), fasta, len(fasta), context_len,
                                                  ctypes.byref(e), ctypes.byref(s), ctypes.byref(st)))
         return self._take(e), self._take(s), {n: int(getattr(st, n)) for n, _ in VcfStats._fields_}
+
+    def leds_tokenised_on_device(self):
+        return bool(self._lib.edsx_leds_tokenised_on_device(self._h))
 
     # ---- symbol-range partition of the merge (multi-GPU, see multigpu.MergeSharder)
     def leds_merge_range(self, eds, seds=None, context_len=1, compact=True, head_sentinel=False, tail_sentinel=False):

@@ -181,6 +181,8 @@ int edsx_leds_merge(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const ui
     });
 }
 
+int edsx_leds_tokenised_on_device(const edsx_ctx* ctx) { return ctx && ctx->merge.tokenised_on_device() ? 1 : 0; }
+
 int edsx_leds_merge_range(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const uint8_t* seds, size_t seds_size,
                           uint32_t context_len, int compact, int head_sentinel, int tail_sentinel, edsx_buf* leds,
                           edsx_buf* seds_out, int* head_intact, int* tail_intact)

@@ -243,6 +243,146 @@ __global__ void k_fin_write(FinParams p, u64 nstr)
     }
 }
 
+
+// ---- device tokenisers ------------------------------------------------------------------------------
+// The .eds / .seds text goes to HBM as it is and is tokenised there (eds.cpp:39-155 / :268-355 rules) straight into
+// the layout above: no host arrays, no per-array upload.  The kernels only accept text every byte of which they can
+// place (no whitespace before the end, braces alternate, no comma outside braces, ids are digits that fit an int,
+// no empty source set); anything else raises `bad`, and the host tokenisers — which own the reference's error texts
+// and its treatment of odd but legal text — take the input instead.
+//   marks    brace bytes publish 2*(i+1)+is_open; an inclusive max-scan gives every byte the last brace at or
+//            before it, i.e. whether it sits inside a group
+//   counts   per byte: characters | string starts << 32 (one sum-scan), symbol starts (a second one)
+struct TokCtl { u64 n, bad, total_cs, total_sym, maxid, total_sets, pad0, pad1; };
+
+__device__ __forceinline__ bool tok_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+__global__ void k_tok_mark(const uint8_t* __restrict__ raw, u64 n, u64* __restrict__ bm, TokCtl* ctl, int seds)
+{
+    bool bad = false;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const uint8_t c = raw[i];
+        bm[i] = c == '{' ? 2 * (i + 1) + 1 : (c == '}' ? 2 * (i + 1) : 0);
+        if (tok_ws(c)) bad = true;
+        if (seds && !(c == '{' || c == '}' || c == ',' || (c >= '0' && c <= '9'))) bad = true;
+    }
+    if (bad) ctl->bad = 1;
+}
+
+// .eds: cs[i] = is_char | string_start << 32, sy[i] = symbol_start
+__global__ void k_tok_eds_flags(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ last, u64* __restrict__ cs,
+                                u64* __restrict__ sy, TokCtl* ctl)
+{
+    bool bad = false;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const uint8_t c = raw[i];
+        const bool inside = i > 0 && (last[i - 1] & 1);
+        u64 ch = 0, st = 0, sm = 0;
+        if (c == '{') { if (inside) bad = true; st = 1; sm = 1; }
+        else if (c == '}') { if (!inside) bad = true; }
+        else if (c == ',') { if (!inside) bad = true; st = 1; }
+        else {
+            ch = 1;
+            if (!inside && (i == 0 || raw[i - 1] == '}')) { st = 1; sm = 1; }      // a bare run opens a symbol (eds.cpp:848-878)
+        }
+        if (i == n - 1 && (last[i] & 1)) bad = true;                                 // unterminated group
+        cs[i] = ch | (st << 32);
+        sy[i] = sm;
+    }
+    if (bad) ctl->bad = 1;
+}
+
+__global__ void k_tok_eds_fill(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ cs, const u64* __restrict__ css,
+                               const u64* __restrict__ sy, const u64* __restrict__ sys, uint8_t* __restrict__ chars,
+                               u64* __restrict__ str_off, u64* __restrict__ sym_first, const TokCtl* ctl)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 f = cs[i], sc = css[i];
+        const u64 cpos = sc & 0xffffffffull, sidx = sc >> 32;
+        if (f & 1) chars[cpos] = raw[i];
+        if (f >> 32) str_off[sidx] = cpos;
+        if (sy[i]) sym_first[sys[i]] = sidx;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        str_off[ctl->total_cs >> 32] = ctl->total_cs & 0xffffffffull;
+        sym_first[ctl->total_sym] = ctl->total_cs >> 32;
+    }
+}
+
+__global__ void k_tok_leaves(const u64* __restrict__ str_off, u64 m, u32* __restrict__ left, u32* __restrict__ right,
+                             u32* __restrict__ elen)
+{
+    for (u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x; s < m; s += (u64)gridDim.x * blockDim.x) {
+        left[s] = LEAF; right[s] = (u32)s; elen[s] = (u32)(str_off[s + 1] - str_off[s]);
+    }
+}
+
+__global__ void k_tok_syms(const u64* __restrict__ sym_first, const u64* __restrict__ str_off, u64 n0, SymArrays s)
+{
+    for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n0; k += (u64)gridDim.x * blockDim.x) {
+        const u64 f = sym_first[k], sz = sym_first[k + 1] - f;
+        s.size[k] = sz; s.ent_off[k] = f; s.len1[k] = sz == 1 ? str_off[f + 1] - str_off[f] : 0;
+    }
+}
+
+// .seds: an id is a maximal run of digits; value -> ok?  (std::stoi range, eds.cpp:336-349)
+__device__ __forceinline__ bool tok_number(const uint8_t* raw, u64 i, u64 n, u64& val)
+{
+    val = 0;
+    u64 j = i;
+    for (; j < n && raw[j] >= '0' && raw[j] <= '9'; j++) {
+        val = val * 10 + (raw[j] - '0');
+        if (val > 2147483647ull) return false;
+    }
+    return true;
+}
+
+// cs[i] = set_start | id_start << 32
+__global__ void k_tok_seds_flags(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ last, u64* __restrict__ cs,
+                                 TokCtl* ctl)
+{
+    bool bad = false;
+    u64 mx = 0;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const uint8_t c = raw[i];
+        const bool inside = i > 0 && (last[i - 1] & 1);
+        u64 ss = 0, ns = 0;
+        if (c == '{') { if (inside) bad = true; ss = 1; }
+        else if (c == '}') { if (!inside) bad = true; }
+        else {
+            if (!inside) bad = true;
+            if (c != ',' && (i == 0 || !(raw[i - 1] >= '0' && raw[i - 1] <= '9'))) {
+                u64 v;
+                if (!tok_number(raw, i, n, v)) bad = true;
+                mx = v > mx ? v : mx;
+                ns = 1;
+            }
+        }
+        if (i == n - 1 && (last[i] & 1)) bad = true;
+        cs[i] = ss | (ns << 32);
+    }
+    if (bad) ctl->bad = 1;
+    if (mx) atomicMax((unsigned long long*)&ctl->maxid, (unsigned long long)mx);
+}
+
+__global__ void k_tok_seds_fill(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ last, const u64* __restrict__ cs,
+                                const u64* __restrict__ css, u64* __restrict__ bits, u32 W, TokCtl* ctl)
+{
+    bool bad = false;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        if (cs[i] >> 32) {
+            u64 v;
+            tok_number(raw, i, n, v);
+            const u64 set = (css[i] & 0xffffffffull) - 1;                            // sets opened before this byte
+            atomicOr((unsigned long long*)&bits[set * W + (v >> 6)], 1ull << (v & 63));
+        } else if (raw[i] == '}') {
+            const u64 open = (last[i - 1] >> 1) - 1;                                 // its '{' (validated by the flags pass)
+            if ((css[i] >> 32) == (css[open] >> 32)) bad = true;                     // empty path set
+        }
+    }
+    if (bad) ctl->bad = 1;
+}
+
 // ---- host ---------------------------------------------------------------------------------------
 namespace {
 
@@ -406,12 +546,98 @@ void grow_keep(DevBuf& b, size_t used, size_t need, hipStream_t st)
 
 } // namespace
 
+// Tokenise on the device (kernels above).  false: the text is not plain, or there is none; the caller then runs the
+// host tokenisers.  On success chars / str_off / the leaf entries / the round-0 symbol arrays / the source bitsets
+// are in place in HBM.
+bool MergePipeline::tokenize_device(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, bool linear,
+                                    hipStream_t st, u64& n0, u64& m, u32& W, bool& head_single, bool& tail_single, u64& head_len)
+{
+    { const char* e = getenv("EDSX_HOST_TOKENIZER"); if (e && atoi(e)) return false; }      // A/B switch for the parity tests
+    size_t end = eds_n, send = linear ? seds_n : 0;
+    while (end && std::isspace(eds[end - 1])) end--;
+    while (send && std::isspace(seds[send - 1])) send--;
+    if (end == 0 || end >= 0xfffffff0ull || (linear && (send == 0 || send >= 0xfffffff0ull))) return false;
+    const size_t nmax = std::max(end, send);
+    d_raw_.ensure(nmax + 16);
+    for (DevBuf* b : {&tk_a_, &tk_b_, &tk_c_, &tk_d_, &tk_e_}) b->ensure(8 * (nmax + 2));
+    scan_tmp_.ensure(8 * ((nmax + 2) / SCAN_TILE + 4));
+    TokCtl* ctl = ctl_.as<TokCtl>();
+    TokCtl h{};
+    h.n = end;
+    EDSX_HIP(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    EDSX_HIP(hipMemcpyAsync(d_raw_.ptr, eds, end, hipMemcpyHostToDevice, st));
+    const uint8_t* raw = d_raw_.as<uint8_t>();
+    u64 *a = tk_a_.as<u64>(), *b = tk_b_.as<u64>(), *c = tk_c_.as<u64>(), *d = tk_d_.as<u64>(), *e = tk_e_.as<u64>();
+    hipLaunchKernelGGL(k_tok_mark, dim3(2048), dim3(256), 0, st, raw, (u64)end, a, ctl, 0);
+    inclusive_max_scan_u64(a, a, &ctl->n, &ctl->pad0, scan_tmp_.as<u64>(), st);
+    hipLaunchKernelGGL(k_tok_eds_flags, dim3(2048), dim3(256), 0, st, raw, (u64)end, a, b, c, ctl);
+    exclusive_scan_u64(b, d, &ctl->n, &ctl->total_cs, scan_tmp_.as<u64>(), st);
+    exclusive_scan_u64(c, e, &ctl->n, &ctl->total_sym, scan_tmp_.as<u64>(), st);
+    EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    if (h.bad) return false;
+    const u64 nchars = h.total_cs & 0xffffffffull;
+    m = h.total_cs >> 32;
+    n0 = h.total_sym;
+    if (n0 == 0 || m == 0 || m >= 0xfffffff0ull) return false;
+    d_chars_.ensure(nchars + 16);
+    d_str_off_.ensure(8 * (m + 1));
+    d_sym_first_.ensure(8 * (n0 + 1));
+    hipLaunchKernelGGL(k_tok_eds_fill, dim3(2048), dim3(256), 0, st, raw, (u64)end, b, d, c, e, d_chars_.as<uint8_t>(),
+                       d_str_off_.as<u64>(), d_sym_first_.as<u64>(), ctl);
+    const size_t pool_cap = std::max<size_t>(2 * m + 1024, 4096);
+    left_.ensure(4 * pool_cap); right_.ensure(4 * pool_cap); elen_.ensure(4 * pool_cap);
+    hipLaunchKernelGGL(k_tok_leaves, dim3(2048), dim3(256), 0, st, d_str_off_.as<u64>(), m, left_.as<u32>(), right_.as<u32>(),
+                       elen_.as<u32>());
+    for (int k = 0; k < 2; k++) { size_[k].ensure(8 * (n0 + 1)); ent_off_[k].ensure(8 * (n0 + 1)); len1_[k].ensure(8 * (n0 + 1)); }
+    hipLaunchKernelGGL(k_tok_syms, dim3(2048), dim3(256), 0, st, d_sym_first_.as<u64>(), d_str_off_.as<u64>(), n0,
+                       SymArrays{size_[0].as<u64>(), ent_off_[0].as<u64>(), len1_[0].as<u64>()});
+    u64 sf_head[2] = {0, 0}, sf_tail[2] = {0, 0}, so_head[2] = {0, 0};
+    EDSX_HIP(hipMemcpyAsync(sf_head, d_sym_first_.as<u64>(), 16, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(sf_tail, d_sym_first_.as<u64>() + (n0 - 1), 16, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(so_head, d_str_off_.as<u64>(), 16, hipMemcpyDeviceToHost, st));
+    if (linear) {
+        h = TokCtl{};
+        h.n = send;
+        EDSX_HIP(hipStreamSynchronize(st));                      // the small read-backs above land before h is reused
+        EDSX_HIP(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, st));
+        EDSX_HIP(hipMemcpyAsync(d_raw_.ptr, seds, send, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_tok_mark, dim3(2048), dim3(256), 0, st, raw, (u64)send, a, ctl, 1);
+        inclusive_max_scan_u64(a, a, &ctl->n, &ctl->pad0, scan_tmp_.as<u64>(), st);
+        hipLaunchKernelGGL(k_tok_seds_flags, dim3(2048), dim3(256), 0, st, raw, (u64)send, a, b, ctl);
+        exclusive_scan_u64(b, d, &ctl->n, &ctl->total_sets, scan_tmp_.as<u64>(), st);
+        EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        if (h.bad || (h.total_sets & 0xffffffffull) != m) return false;   // the host path words the error
+        W = (u32)(h.maxid / 64 + 1);
+        bits_.ensure(8 * pool_cap * W);
+        EDSX_HIP(hipMemsetAsync(bits_.ptr, 0, 8 * (size_t)m * W, st));
+        hipLaunchKernelGGL(k_tok_seds_fill, dim3(2048), dim3(256), 0, st, raw, (u64)send, a, b, d, bits_.as<u64>(), W, ctl);
+        EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+    }
+    EDSX_HIP(hipStreamSynchronize(st));
+    EDSX_HIP(hipGetLastError());
+    if (linear && h.bad) return false;
+    head_single = sf_head[1] - sf_head[0] == 1;
+    tail_single = sf_tail[1] - sf_tail[0] == 1;
+    head_len = so_head[1] - so_head[0];
+    return true;
+}
+
 void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l, bool compact,
                         std::string& out, std::string& seds_out, hipStream_t st, MergeShard* shard)
 {
     if (l == 0) throw ParamError("context_length must be > 0 for l-EDS transformation");   // :322-324
     const bool linear = seds != nullptr;
 
+    // ---- tokenise: on the device when the text is plain (see "device tokenisers"), else on the host
+    ctl_.ensure(8 * 16);
+    u64 n0 = 0, m = 0, head_len = 0;
+    u32 W = 1;
+    bool head_single = false, tail_single = false;
+    const bool on_device = tokenize_device(eds, eds_n, seds, seds_n, linear, st, n0, m, W, head_single, tail_single, head_len);
+    tokenised_on_device_ = on_device;
+    if (!on_device) {
     // ---- host tokeniser: eds.cpp:39-155 (same error texts)
     std::vector<uint8_t> chars;
     std::vector<u64> str_off{0}, sym_first{0};
@@ -437,10 +663,9 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
             }
         }
     }
-    const u64 n0 = sym_first.size() - 1, m = str_off.size() - 1;
+    n0 = sym_first.size() - 1; m = str_off.size() - 1;
 
     // ---- sources: eds.cpp:268-355 -> bitsets
-    u32 W = 1;
     std::vector<u64> bits;
     std::vector<SedsPart> sparts;
     u64 par_sets = 0;
@@ -508,13 +733,8 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
         return;
     }
     if (m >= 0xfffffff0ull) throw FormatError("EDS has too many strings for this build");
-    if (shard) {
-        shard->head_intact = shard->tail_intact = true;
-        if ((shard->head_sentinel && sym_first[1] - sym_first[0] != 1) ||
-            (shard->tail_sentinel && sym_first[n0] - sym_first[n0 - 1] != 1) ||
-            ((shard->head_sentinel && shard->tail_sentinel) && n0 < 3))
-            throw ParamError("a sentinel of a symbol range must be a single-string symbol of its own");
-    }
+    head_single = sym_first[1] - sym_first[0] == 1; tail_single = sym_first[n0] - sym_first[n0 - 1] == 1;
+    head_len = str_off[1] - str_off[0];
 
     // ---- upload
     d_chars_.ensure(chars.size() + 16);
@@ -546,9 +766,15 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
         EDSX_HIP(hipMemcpyAsync(len1_[0].ptr, hl.data(), 8 * n0, hipMemcpyHostToDevice, st));
         EDSX_HIP(hipStreamSynchronize(st));
     }
+    }
+    if (shard) {
+        shard->head_intact = shard->tail_intact = true;
+        if ((shard->head_sentinel && !head_single) || (shard->tail_sentinel && !tail_single) ||
+            ((shard->head_sentinel && shard->tail_sentinel) && n0 < 3))
+            throw ParamError("a sentinel of a symbol range must be a single-string symbol of its own");
+    }
     a_.ensure(8 * (n0 + 2)); b_.ensure(8 * (n0 + 2)); c_.ensure(8 * (n0 + 2)); d_.ensure(8 * (n0 + 2)); e_.ensure(8 * (n0 + 2));
     scan_tmp_.ensure(8 * ((n0 + 2) / SCAN_TILE + 2));
-    ctl_.ensure(8 * 16);
     u64* ctl = ctl_.as<u64>();         // [0]=n  [1]=any  [2]=n_new  [3]=total_new  [4]=err_pos  [5]=err_big  [6]=scratch
 
     u64 n = n0, pool_used = m;
@@ -651,7 +877,7 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
         if (linear) seds_out.pop_back();
     }
     if (shard && shard->head_sentinel && shard->head_intact) {   // the left neighbour prints the shared sentinel
-        out.erase(0, (size_t)(str_off[1] - str_off[0]) + (compact ? 0 : 2));
+        out.erase(0, (size_t)head_len + (compact ? 0 : 2));
         if (linear) seds_out.erase(0, seds_out.find('}') + 1);
     }
 }

@@ -73,6 +73,11 @@ int edsx_leds_merge(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size,
                     const uint8_t* seds, size_t seds_size, uint32_t context_len, int compact,
                     edsx_buf* leds, edsx_buf* seds_out);
 
+/* 1 when the last edsx_leds_merge / _range call on this context tokenised its .eds/.seds text on the GPU (plain text:
+ * no inner whitespace, no comma outside braces, well-formed), 0 when the host tokenisers took it (anything else,
+ * and every input that ends in one of the reference's format errors). */
+int edsx_leds_tokenised_on_device(const edsx_ctx* ctx);
+
 /* VCF + FASTA -> EDS (context_len == 0) or l-EDS (> 0) + sEDS; stats may be NULL. */
 int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size,
                        const uint8_t* fasta, size_t fasta_size, uint32_t context_len,

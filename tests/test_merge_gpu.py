@@ -203,3 +203,68 @@ def test_randomized_campaign(ctx):
         got.pop("code", None)
         assert got == want, (it, desc, l, compact)
     assert ran > 300
+
+
+def test_device_tokeniser_is_taken_and_equals_the_host_tokenisers(ctx):
+    """Plain text (what the tools write) is tokenised on the GPU; text the kernels cannot place byte for byte goes to
+    the host tokenisers.  Both ways must give the same bytes (EDSX_HOST_TOKENIZER=1 forces the host path), and which
+    way was taken is visible through edsx_leds_tokenised_on_device."""
+    from merge_cases import campaign_eds
+    rng = random.Random(5150)
+    on_dev = on_host = 0
+    for it in range(250):
+        eds, seds, l, compact, desc = campaign_eds(rng)
+        if desc[-1] > 100000:
+            continue
+        got = _run(ctx, eds, seds, l, compact)
+        dev = ctx.leds_tokenised_on_device()
+        os.environ["EDSX_HOST_TOKENIZER"] = "1"
+        try:
+            host = _run(ctx, eds, seds, l, compact)
+            assert not ctx.leds_tokenised_on_device()
+        finally:
+            del os.environ["EDSX_HOST_TOKENIZER"]
+        assert got == host, (it, desc)
+        plain = not any(ch in eds[:len(eds.rstrip())] for ch in b" \n\t\r") and "error" not in got
+        if plain and eds.strip():
+            assert dev, (it, eds[:80])
+        on_dev += dev
+        on_host += not dev
+    assert on_dev > 100 and on_host > 10
+
+
+def test_device_tokeniser_hands_odd_text_to_the_host(ctx):
+    cases = [
+        (b"{A,C} GG{T}", None),              # inner whitespace
+        (b"A,C{G,T}AAAA", None),             # comma outside braces: the bare run becomes a degenerate symbol
+        (b"{A{C}}", None),                   # nesting
+        (b"{A,C}}", None),                   # stray brace
+        (b"{A,C", None),                     # unterminated
+        (b"{A,C}{G}", b"{1}{2}"),            # source count differs from the cardinality
+        (b"{A,C}{G}", b"{1}{}{0}"),          # empty path set
+        (b"{A,C}{G}", b"{1}{2x}{0}"),        # character that does not belong
+        (b"{A,C}{G}", b"{1}{99999999999}{0}"),
+        (b"", None), (b"\n", None),
+    ]
+    for eds, seds in cases:
+        try:
+            w = o.merge(eds, seds, 2, True)
+            want = {"out": w[0].decode(), "seds_out": w[1].decode()}
+        except o.OracleError as ex:
+            want = {"error": str(ex)}
+        got = _run(ctx, eds, seds, 2, True)
+        got.pop("code", None)
+        assert got == want, (eds, seds)
+        assert not ctx.leds_tokenised_on_device(), (eds, seds)
+    # plain text, all spellings: on the device
+    for eds, seds in [(b"{A,C}GGGG{T,}\n", None), (b"ACGT", None), (b"{}{A}{,}", None), (b"{A,C}{G}", b"{1,2}{0,3}{0}\n"),
+                      (b"{AC}GT{A,C}", b"{0}{0}{007}{1,,2}")]:
+        try:
+            w = o.merge(eds, seds, 3, False)
+            want = {"out": w[0].decode(), "seds_out": w[1].decode()}
+        except o.OracleError as ex:
+            want = {"error": str(ex)}
+        got = _run(ctx, eds, seds, 3, False)
+        got.pop("code", None)
+        assert got == want, (eds, seds)
+        assert ctx.leds_tokenised_on_device(), (eds, seds)
