@@ -69,6 +69,7 @@ def load_library():
     lib.edsx_vcf_transform.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                        ctypes.c_size_t, ctypes.c_uint32, P(_Buf), P(_Buf), P(VcfStats)]
     lib.edsx_leds_tokenised_on_device.argtypes = [ctypes.c_void_p]
+    lib.edsx_vcf_tokenised_on_device.argtypes = [ctypes.c_void_p]
     lib.edsx_leds_merge_range.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                           ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           P(_Buf), P(_Buf), P(ctypes.c_int), P(ctypes.c_int)]
@@ -154,6 +155,9 @@ class Context:
         self._check(self._lib.edsx_vcf_transform(self._h, vcf, len(vcf), fasta, len(fasta), context_len,
                                                  ctypes.byref(e), ctypes.byref(s), ctypes.byref(st)))
         return self._take(e), self._take(s), {n: int(getattr(st, n)) for n, _ in VcfStats._fields_}
+
+    def vcf_tokenised_on_device(self):
+        return bool(self._lib.edsx_vcf_tokenised_on_device(self._h))
 
     def leds_tokenised_on_device(self):
         return bool(self._lib.edsx_leds_tokenised_on_device(self._h))

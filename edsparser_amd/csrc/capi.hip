@@ -207,6 +207,8 @@ int edsx_leds_merge_range(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, co
     });
 }
 
+int edsx_vcf_tokenised_on_device(const edsx_ctx* ctx) { return ctx && ctx->vcf.tokenised_on_device() ? 1 : 0; }
+
 int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, const uint8_t* fasta, size_t fasta_size,
                        uint32_t context_len, edsx_buf* eds, edsx_buf* seds, edsx_vcf_stats* stats)
 {

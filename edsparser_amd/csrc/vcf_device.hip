@@ -361,6 +361,151 @@ __global__ void k_tail(VcfDev d, u64 cur, u64 clen, uint8_t* eo, uint8_t* so)
     for (u64 i = t; i < clen; i += (u64)gridDim.x * blockDim.x) eo[1 + i] = d.refc[c0 + i];
 }
 
+
+// ---- device tokeniser (parse_vcf_line :232-326, parse_alt_field :142-176, parse_genotype :190-216) -------
+// The VCF text goes to HBM as it is; record lines are found with a flag scan, a thread per record line walks its
+// fields twice (count, then fill in sorted order) and writes the record SoA above — no host records, no uploads
+// of eight arrays.  The kernels accept the *plain* spelling only: tab-separated lines without empty fields and
+// with at least five of them, POS all digits (<= 19), no symbolic ALT other than <DEL>/<INS>, genotype alleles
+// that are "." or all digits (<= 9), no '\r'.  Anything else — the whitespace-separated fallback of :262-279,
+// malformed lines, unsupported structural variants (their warnings are in file order), signs or junk that
+// std::stoull/stoi would swallow, POS 0 — raises `bad`, and the host tokeniser takes the whole file.
+struct VtCtl { u64 n, bad, nrec, max_samples, t_alt, t_altc, t_pair, t_all; };
+
+struct VtSink {                      // fill pass: where record j's pieces go
+    u64* altoff; u64 altc_base; uint8_t* altchars; u64* pa0; u64 all_base; int* alleles;
+};
+struct VtCounts { u64 pos; u64 reflen, nalt, altc, ngt, nall; };
+
+template <bool FILL>
+__device__ bool vt_parse(const uint8_t* __restrict__ raw, u64 lo, u64 hi, VtCounts& c, const VtSink& k)
+{
+    c = VtCounts{0, 0, 0, 0, 0, 0};
+    u64 fs = lo, ref_lo = 0;
+    int f = 0;
+    for (u64 i = lo; i <= hi; i++) {
+        if (i < hi && raw[i] != '\t') continue;
+        const u64 fe = i;
+        if (fe == fs) return false;                                      // empty token: the reference drops it (:262-268)
+        if (f == 1) {
+            if (fe - fs > 19) return false;
+            u64 v = 0;
+            for (u64 t = fs; t < fe; t++) { const uint8_t ch = raw[t]; if (ch < '0' || ch > '9') return false; v = v * 10 + (ch - '0'); }
+            c.pos = v;
+        } else if (f == 3) { ref_lo = fs; c.reflen = fe - fs; }
+        else if (f == 4) {
+            u64 t = fs;
+            while (t < fe) {                                             // std::getline(ss, a, ',')
+                u64 e = t;
+                while (e < fe && raw[e] != ',') e++;
+                const u64 len = e - t;
+                const uint8_t* src = raw + t;
+                u64 alen = len;
+                if (len && raw[t] == '<' && raw[e - 1] == '>') {
+                    if (len == 5 && raw[t + 1] == 'D' && raw[t + 2] == 'E' && raw[t + 3] == 'L') alen = 0;
+                    else if (len == 5 && raw[t + 1] == 'I' && raw[t + 2] == 'N' && raw[t + 3] == 'S') { src = raw + ref_lo; alen = c.reflen; }
+                    else return false;                                   // unsupported SV: warning + skip on the host
+                }
+                if (FILL) {
+                    k.altoff[c.nalt] = k.altc_base + c.altc;
+                    for (u64 x = 0; x < alen; x++) k.altchars[k.altc_base + c.altc + x] = src[x];
+                }
+                c.nalt++; c.altc += alen;
+                t = e + 1;
+            }
+        } else if (f >= 9) {
+            u64 ge = fs;
+            bool slash = false;
+            while (ge < fe && raw[ge] != ':') { slash |= raw[ge] == '/'; ge++; }
+            const uint8_t delim = slash ? '/' : '|';
+            if (FILL) k.pa0[c.ngt] = k.all_base + c.nall;
+            u64 t = fs;
+            while (t < ge) {
+                u64 e = t;
+                while (e < ge && raw[e] != delim) e++;
+                const u64 len = e - t;
+                if (len && !(len == 1 && raw[t] == '.')) {
+                    if (len > 9) return false;
+                    int v = 0;
+                    for (u64 x = t; x < e; x++) { const uint8_t ch = raw[x]; if (ch < '0' || ch > '9') return false; v = v * 10 + (ch - '0'); }
+                    if (FILL) k.alleles[k.all_base + c.nall] = v;
+                    c.nall++;
+                }
+                t = e + 1;
+            }
+            c.ngt++;
+        }
+        f++;
+        fs = i + 1;
+    }
+    return f >= 5;
+}
+
+__global__ void k_vt_lines(const uint8_t* __restrict__ raw, u64 n, u64* __restrict__ flag, VtCtl* ctl)
+{
+    bool bad = false;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const uint8_t c = raw[i];
+        if (c == '\r') bad = true;
+        flag[i] = (i == 0 || raw[i - 1] == '\n') && c != '\n' && c != '#';
+    }
+    if (bad) ctl->bad = 1;
+}
+__global__ void k_vt_scatter(const u64* __restrict__ flag, const u64* __restrict__ idx, u64 n, u64* __restrict__ lstart)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (flag[i]) lstart[idx[i]] = i;
+}
+__device__ __forceinline__ u64 vt_line_end(const uint8_t* raw, u64 lo, u64 n)
+{
+    u64 hi = lo;
+    while (hi < n && raw[hi] != '\n') hi++;
+    return hi;
+}
+struct VtRec { u64* pos; u64* reflen; u64* nalt; u64* altc; u64* ngt; u64* nall; };
+__global__ void k_vt_count(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ lstart, u64 nrec, VtRec r, VtCtl* ctl)
+{
+    bool bad = false;
+    u64 mx = 0;
+    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < nrec; j += (u64)gridDim.x * blockDim.x) {
+        const u64 lo = lstart[j];
+        VtCounts c;
+        if (!vt_parse<false>(raw, lo, vt_line_end(raw, lo, n), c, VtSink{})) bad = true;
+        if (c.pos == 0 || c.pos - 1 + c.reflen < c.pos - 1) bad = true;      // wrapped positions: host sweep (see run)
+        r.pos[j] = c.pos; r.reflen[j] = c.reflen; r.nalt[j] = c.nalt; r.altc[j] = c.altc; r.ngt[j] = c.ngt; r.nall[j] = c.nall;
+        mx = c.ngt > mx ? c.ngt : mx;
+    }
+    if (bad) ctl->bad = 1;
+    if (mx) atomicMax((unsigned long long*)&ctl->max_samples, (unsigned long long)mx);
+}
+// counts in sorted order (inputs of the four offset scans)
+__global__ void k_vt_gather(VtRec r, const u32* __restrict__ order, u64 nrec, u64* __restrict__ a, u64* __restrict__ b,
+                            u64* __restrict__ c, u64* __restrict__ d)
+{
+    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < nrec; j += (u64)gridDim.x * blockDim.x) {
+        const u64 i = order[j];
+        a[j] = r.nalt[i]; b[j] = r.altc[i]; c[j] = r.ngt[i]; d[j] = r.nall[i];
+    }
+}
+struct VtOut { u64* start; u64* reflen; u64* alt0; u64* altoff; uint8_t* altchars; u64* pair0; u64* pa0; int* alleles;
+               const u64* altc0; const u64* gtc0; };
+__global__ void k_vt_fill(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ lstart, const u32* __restrict__ order,
+                          u64 nrec, VtOut o, const VtCtl* ctl)
+{
+    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < nrec; j += (u64)gridDim.x * blockDim.x) {
+        const u64 lo = lstart[order[j]];
+        VtCounts c;
+        VtSink k{o.altoff + o.alt0[j], o.altc0[j], o.altchars, o.pa0 + o.pair0[j], o.gtc0[j], o.alleles};
+        vt_parse<true>(raw, lo, vt_line_end(raw, lo, n), c, k);
+        o.start[j] = c.pos - 1;
+        o.reflen[j] = c.reflen;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        o.alt0[nrec] = ctl->t_alt; o.altoff[ctl->t_alt] = ctl->t_altc;
+        o.pair0[nrec] = ctl->t_pair; o.pa0[ctl->t_pair] = ctl->t_all;
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------------
 namespace {
 
@@ -578,6 +723,70 @@ void vcf_sort_order(const u64* pos, size_t n, u32* order_out)
     for (size_t i = 0; i < n; i++) order_out[i] = order[i].second;
 }
 
+// Tokenise on the device (kernels above).  false: the file is not plain; the caller runs the host tokeniser.  On success
+// the record SoA (sorted order) is in place in HBM and the counters are set.
+bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, hipStream_t st, u64& nrec, u64& max_samples,
+                                  VcfCounters& stats)
+{
+    { const char* e = getenv("EDSX_HOST_TOKENIZER"); if (e && atoi(e)) return false; }      // A/B switch for the parity tests
+    nrec = 0; max_samples = 0;
+    if (n == 0) return false;
+    vt_raw_.ensure(n + 16);
+    vt_flag_.ensure(8 * (n + 2)); vt_idx_.ensure(8 * (n + 2));
+    scan_tmp_.ensure(8 * ((n + 2) / SCAN_TILE + 4));
+    ctl_.ensure(8 * 32);
+    VtCtl* ctl = reinterpret_cast<VtCtl*>(ctl_.as<u64>() + 16);
+    VtCtl h{};
+    h.n = n;
+    EDSX_HIP(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    EDSX_HIP(hipMemcpyAsync(vt_raw_.ptr, vcf, n, hipMemcpyHostToDevice, st));
+    const uint8_t* raw = vt_raw_.as<uint8_t>();
+    hipLaunchKernelGGL(k_vt_lines, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_flag_.as<u64>(), ctl);
+    exclusive_scan_u64(vt_flag_.as<u64>(), vt_idx_.as<u64>(), &ctl->n, &ctl->nrec, scan_tmp_.as<u64>(), st);
+    EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    if (h.bad || h.nrec >= 0xffffffffull) return false;
+    const u64 nr = h.nrec;
+    stats.total_variants = stats.processed_variants = nr;
+    if (nr == 0) return true;
+    vt_lstart_.ensure(8 * (nr + 1));
+    hipLaunchKernelGGL(k_vt_scatter, dim3(2048), dim3(256), 0, st, vt_flag_.as<u64>(), vt_idx_.as<u64>(), (u64)n, vt_lstart_.as<u64>());
+    for (DevBuf* b : {&vt_pos_, &vt_reflen_, &vt_nalt_, &vt_altc_, &vt_ngt_, &vt_nall_, &vt_s1_, &vt_s2_, &vt_s3_, &vt_s4_}) b->ensure(8 * (nr + 2));
+    VtRec rec{vt_pos_.as<u64>(), vt_reflen_.as<u64>(), vt_nalt_.as<u64>(), vt_altc_.as<u64>(), vt_ngt_.as<u64>(), vt_nall_.as<u64>()};
+    hipLaunchKernelGGL(k_vt_count, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_lstart_.as<u64>(), nr, rec, ctl);
+    std::vector<u64> hpos(nr);
+    EDSX_HIP(hipMemcpyAsync(hpos.data(), vt_pos_.ptr, 8 * nr, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    if (h.bad) return false;
+    // the reference's unstable std::sort (:715-718) on (pos, file index) pairs, as on the host path
+    std::vector<u32> order(nr);
+    if (presorted) for (u64 i = 0; i < nr; i++) order[i] = (u32)i;
+    else vcf_sort_order(hpos.data(), nr, order.data());
+    vt_order_.ensure(4 * (nr + 1));
+    EDSX_HIP(hipMemcpyAsync(vt_order_.ptr, order.data(), 4 * nr, hipMemcpyHostToDevice, st));
+    h.n = nr;
+    EDSX_HIP(hipMemcpyAsync(&ctl->n, &h.n, 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_vt_gather, dim3(2048), dim3(256), 0, st, rec, vt_order_.as<u32>(), nr, vt_s1_.as<u64>(), vt_s2_.as<u64>(),
+                       vt_s3_.as<u64>(), vt_s4_.as<u64>());
+    alt0_.ensure(8 * (nr + 2)); pair0_.ensure(8 * (nr + 2)); start_.ensure(8 * (nr + 2)); reflen_.ensure(8 * (nr + 2));
+    exclusive_scan_u64(vt_s1_.as<u64>(), alt0_.as<u64>(), &ctl->n, &ctl->t_alt, scan_tmp_.as<u64>(), st);
+    exclusive_scan_u64(vt_s2_.as<u64>(), vt_s2_.as<u64>(), &ctl->n, &ctl->t_altc, scan_tmp_.as<u64>(), st);
+    exclusive_scan_u64(vt_s3_.as<u64>(), pair0_.as<u64>(), &ctl->n, &ctl->t_pair, scan_tmp_.as<u64>(), st);
+    exclusive_scan_u64(vt_s4_.as<u64>(), vt_s4_.as<u64>(), &ctl->n, &ctl->t_all, scan_tmp_.as<u64>(), st);
+    EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));                          // also: `order` stays alive until its upload is done
+    altoff_.ensure(8 * (h.t_alt + 2)); altchars_.ensure(h.t_altc + 16); pa0_.ensure(8 * (h.t_pair + 2)); alleles_.ensure(4 * (h.t_all + 4));
+    VtOut o{start_.as<u64>(), reflen_.as<u64>(), alt0_.as<u64>(), altoff_.as<u64>(), altchars_.as<uint8_t>(), pair0_.as<u64>(),
+            pa0_.as<u64>(), alleles_.as<int>(), vt_s2_.as<u64>(), vt_s4_.as<u64>()};
+    hipLaunchKernelGGL(k_vt_fill, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_lstart_.as<u64>(), vt_order_.as<u32>(), nr, o, ctl);
+    EDSX_HIP(hipStreamSynchronize(st));
+    EDSX_HIP(hipGetLastError());
+    nrec = nr;
+    max_samples = h.max_samples;
+    return true;
+}
+
 void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, std::string& eds,
                       std::string& seds, VcfCounters& stats, hipStream_t st, const VcfRange& range)
 {
@@ -604,8 +813,14 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     std::vector<VcfPart> parts;
     std::vector<u64> part_base;                              // first global record index of every part
     std::vector<std::pair<u64, u32>> order;                  // (pos, global index in file order), sorted by pos
-    tokenise(vcf, vcf_n, parts, part_base, stats, false);
-    {
+    u64 dev_nrec = 0, dev_max_samples = 0;
+    const bool on_device = tokenize_device(vcf, vcf_n, range.presorted, st, dev_nrec, dev_max_samples, stats);
+    tokenised_on_device_ = on_device;
+    if (!on_device) {
+        stats = VcfCounters();
+        tokenise(vcf, vcf_n, parts, part_base, stats, false);
+    }
+    if (!on_device) {
         const unsigned nt = (unsigned)parts.size();
         // std::sort's permutation depends only on the outcomes of its comparisons, so sorting (pos, index)
         // pairs by pos ends in the order the reference's sort of whole records ends in
@@ -623,7 +838,7 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
         pt = &parts[t];
         return (size_t)(g - part_base[t]);
     };
-    const u64 nrec = order.size();
+    const u64 nrec = on_device ? dev_nrec : order.size();
 
     // a reference with an empty first line has no addressable positions; the reference divides by
     // line_width (UB), refuse instead
@@ -659,13 +874,16 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     d.nrec = nrec; d.cur0 = range.cur0;
 
     u64 cur = range.cur0, ngrp = 0, E = 0, Q = 0;
-    u64 max_samples = 0;
+    u64 max_samples = dev_max_samples;
     GrpArrays ga{};
     HapArrays ha{};
     if (nrec) {
+        std::vector<u64> hstart, hreflen;                         // host path only (the device tokeniser refuses wrapped positions)
+        if (!on_device) {
         // ---- records -> SoA
         // two passes: sizes -> offsets (serial prefix sums), then the fill by several host threads
-        std::vector<u64> hstart(nrec), hreflen(nrec), halt0(nrec + 1), hpair0(nrec + 1);
+        hstart.resize(nrec); hreflen.resize(nrec);
+        std::vector<u64> halt0(nrec + 1), hpair0(nrec + 1);
         std::vector<u64> altc0(nrec + 1), gtc0(nrec + 1);        // first alt char / first allele of record j
         halt0[0] = 0; hpair0[0] = 0; altc0[0] = 0; gtc0[0] = 0;
         for (u64 j = 0; j < nrec; j++) {
@@ -710,6 +928,7 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
         }
         upload(start_, hstart, st); upload(reflen_, hreflen, st); upload(alt0_, halt0, st); upload(altoff_, haltoff, st);
         upload(altchars_, haltchars, st); upload(pair0_, hpair0, st); upload(pa0_, hpa0, st); upload(alleles_, halleles, st);
+        }
         d.start = start_.as<u64>(); d.reflen = reflen_.as<u64>(); d.alt0 = alt0_.as<u64>(); d.altstr_off = altoff_.as<u64>();
         d.altchars = altchars_.as<uint8_t>(); d.pair0 = pair0_.as<u64>(); d.pair_a0 = pa0_.as<u64>(); d.alleles = alleles_.as<int>();
 
@@ -722,7 +941,7 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
         // sort key and no end wraps.  POS 0 (start = 2^64 - 1) or POS near 2^64 ("-5" parses!) break that; such
         // files are swept on the host exactly as the reference does it (running group end per record).
         bool wraps = false;
-        for (u64 j = 0; j < nrec && !wraps; j++) wraps = hstart[j] == ~0ull || hstart[j] + hreflen[j] < hstart[j];
+        for (u64 j = 0; j < hstart.size() && !wraps; j++) wraps = hstart[j] == ~0ull || hstart[j] + hreflen[j] < hstart[j];
         if (!wraps) {
             hipLaunchKernelGGL(k_rec_ends, dim3(1024), dim3(256), 0, st, d.start, d.reflen, nrec, ends_.as<u64>());
             inclusive_max_scan_u64(ends_.as<u64>(), ends_.as<u64>(), ctl + 0, ctl + 2, scan_tmp_.as<u64>(), st);

@@ -83,6 +83,11 @@ int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size,
                        const uint8_t* fasta, size_t fasta_size, uint32_t context_len,
                        edsx_buf* eds, edsx_buf* seds, edsx_vcf_stats* stats);
 
+/* 1 when the last edsx_vcf_transform / _range call on this context tokenised the VCF text on the GPU (plain files:
+ * tab-separated lines without empty fields, POS all digits, no symbolic ALT other than <DEL>/<INS>, alleles "." or
+ * digits, no '\r', no POS 0), 0 when the host tokeniser took the file (everything else). */
+int edsx_vcf_tokenised_on_device(const edsx_ctx* ctx);
+
 /* ---- multi-GPU VCF: partition by reference position ----
  * Groups of overlapping records (vcf_transforms.cpp:482-534) never span a cut placed at a group start, so
  * every GPU walks its own position range and the pieces concatenate to the reference's text with no repair.

@@ -171,3 +171,84 @@ def test_randomized_campaign(ctx):
         except o.OracleError as ex:
             want = {"error": str(ex)}
         assert _run(ctx, vcf, fasta, l) == want, (it, L, nvar, ns, lw, l)
+
+
+def _want(vcf, fasta, l=0):
+    try:
+        e, s, st = o.vcf(vcf, fasta, l)
+        return {"eds": e.decode(), "seds": s.decode(), "stats": st}
+    except o.OracleError as ex:
+        return {"error": str(ex)}
+
+
+def test_device_tokeniser_single_damage_per_file(ctx):
+    """One oddity per small file, every kind the device tokeniser must either place exactly or hand to the host
+    tokeniser: the result must equal the oracle's either way (a wrongly accepted line would show here, where no
+    second oddity in the same file can trigger the fallback for it)."""
+    rng = random.Random(808)
+    gts = ["./.", ".", "1", "0/1/2", "x|1", "1|", "|", "0|1:9:x", ":", "99999999999|0", "0|1\r", "+1|0", " 1|0", "01|1", "1x|0", "|1", "0||1", "0/1|1"]
+    alts = ["<DEL>", "<INS>", "<INV>", "A,<DEL>", "<DUP>,C", ",", "A,,C", "C,", "<>", "<", ".", "*", "<DEL>,<INS>", "ACGTACGT", "<DELX>", "<del>"]
+    poss = ["0", "-5", "+7", " 12", "12abc", "abc", "99999999999999999999999", "18446744073709551615", "0012", "1", "3000"]
+    wholes = ["", "#junk", "chr1", "\t\t\t", "chr1\t12\t.\tA", "chr1 14 . A G . PASS . GT 0|1 1|1", "chr1\t15\t.\tA\tG", "chr1\t16\t.\tA\tG\t.\tPASS\t.\tGT",
+              "\tchr1\t17\t.\tA\tG\t.\tPASS\t.\tGT\t0|1\t0|0", "chr1\t18\t.\tA\tG\t.\tPASS\t.\tGT\t0|1\t", "chr1\t19\t.\tA\tG\t\t.\tPASS\t.\tGT\t0|1"]
+    taken = {True: 0, False: 0}
+    n = 0
+    for kind, choices in (("gt", gts), ("alt", alts), ("pos", poss), ("line", wholes), ("cr", ["\r"]), ("tabs", ["x"])):
+        for ch in choices:
+            for ns in (0, 2):
+                vcf, fasta = _random_vcf(rng, 3000, 25, ns, 60)
+                lines = vcf.decode().split("\n")
+                i = rng.randrange(2, len(lines) - 1)
+                f = lines[i].split("\t")
+                if kind == "gt":
+                    if ns == 0:
+                        continue
+                    f[9 + rng.randrange(ns)] = ch
+                    lines[i] = "\t".join(f)
+                elif kind == "alt":
+                    f[4] = ch
+                    lines[i] = "\t".join(f)
+                elif kind == "pos":
+                    f[1] = ch
+                    lines[i] = "\t".join(f)
+                elif kind == "line":
+                    lines.insert(i, ch)
+                elif kind == "cr":
+                    lines[i] += "\r"
+                else:
+                    lines[i] = lines[i].replace("\t", "\t\t", 1)
+                for tail in ("\n", ""):
+                    v = ("\n".join(lines[:-1]) + tail).encode()
+                    got = _run(ctx, v, fasta, 0)
+                    assert got == _want(v, fasta), (kind, ch, ns, tail, lines[i])
+                    taken[ctx.vcf_tokenised_on_device()] += 1
+                    n += 1
+    assert n > 150 and taken[True] > 20 and taken[False] > 60, taken
+
+
+def test_device_tokeniser_is_taken_and_equals_the_host_tokeniser(ctx):
+    """Plain files go through the device tokeniser; EDSX_HOST_TOKENIZER=1 forces the host tokeniser: same bytes, same
+    counters; shuffled files and duplicate positions included (the sort is the host's in both)."""
+    rng = random.Random(909)
+    for it in range(40):
+        L = rng.choice([100, 1000, 5000, 30000])
+        nvar = max(1, min(L - 12, int(L * rng.choice([0.01, 0.05, 0.2, 0.4]))))
+        ns = rng.choice([0, 1, 2, 8, 64, 70])
+        vcf, fasta = _random_vcf(rng, L, nvar, ns, rng.choice([60, 7, L]))
+        lines = vcf.decode().split("\n")
+        head, body = lines[:2], [x for x in lines[2:] if x]
+        if it % 3 == 1:
+            rng.shuffle(body)
+        if it % 3 == 2:
+            body += [rng.choice(body) for _ in range(len(body) // 2)]
+            rng.shuffle(body)
+        vcf = ("\n".join(head + body) + ("\n" if it % 2 else "")).encode()
+        got = _run(ctx, vcf, fasta, 0)
+        assert ctx.vcf_tokenised_on_device(), it
+        os.environ["EDSX_HOST_TOKENIZER"] = "1"
+        try:
+            host = _run(ctx, vcf, fasta, 0)
+            assert not ctx.vcf_tokenised_on_device()
+        finally:
+            del os.environ["EDSX_HOST_TOKENIZER"]
+        assert got == host == _want(vcf, fasta), it
