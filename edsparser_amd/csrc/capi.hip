@@ -171,13 +171,11 @@ int edsx_leds_merge(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const ui
     if (seds_out) { seds_out->data = nullptr; seds_out->size = 0; }
     return guarded(ctx, [&] {
         if (!leds || !seds_out || (!eds && eds_size)) throw ParamError("null argument");
-        std::string out, sout;
+        HostBytes out, sout;
         static const uint8_t none = 0;
         ctx->merge.run(eds ? eds : &none, eds_size, seds, seds_size, context_len, compact != 0, out, sout, nullptr);
-        take(leds, out.size());
-        std::memcpy(leds->data, out.data(), out.size());
-        take(seds_out, sout.size());
-        std::memcpy(seds_out->data, sout.data(), sout.size());
+        leds->size = out.size; leds->data = out.release();       // the download buffers themselves
+        seds_out->size = sout.size; seds_out->data = sout.release();
     });
 }
 
@@ -193,17 +191,15 @@ int edsx_leds_merge_range(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, co
     if (tail_intact) *tail_intact = 0;
     return guarded(ctx, [&] {
         if (!leds || !seds_out || !head_intact || !tail_intact || (!eds && eds_size)) throw ParamError("null argument");
-        std::string out, sout;
+        HostBytes out, sout;
         static const uint8_t none = 0;
         MergeShard sh;
         sh.head_sentinel = head_sentinel != 0; sh.tail_sentinel = tail_sentinel != 0;
         ctx->merge.run(eds ? eds : &none, eds_size, seds, seds_size, context_len, compact != 0, out, sout, nullptr, &sh);
         *head_intact = sh.head_intact ? 1 : 0;
         *tail_intact = sh.tail_intact ? 1 : 0;
-        take(leds, out.size());
-        std::memcpy(leds->data, out.data(), out.size());
-        take(seds_out, sout.size());
-        std::memcpy(seds_out->data, sout.data(), sout.size());
+        leds->size = out.size; leds->data = out.release();
+        seds_out->size = sout.size; seds_out->data = sout.release();
     });
 }
 
@@ -218,7 +214,7 @@ int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, const
     return guarded(ctx, [&] {
         if (!eds || !seds || (!vcf && vcf_size) || (!fasta && fasta_size)) throw ParamError("null argument");
         static const uint8_t none = 0;
-        std::string e, s;
+        HostBytes e, s;
         VcfCounters c;
         try {
             ctx->vcf.run(vcf ? vcf : &none, vcf_size, fasta ? fasta : &none, fasta_size, e, s, c, nullptr);
@@ -235,16 +231,14 @@ int edsx_vcf_transform(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, const
             stats->variant_groups = c.variant_groups;
         }
         if (context_len > 0) {   // vcf_transforms.cpp:735-755: EDS text -> LINEAR merge with defaults (compact)
-            std::string lo, so;
-            ctx->merge.run(reinterpret_cast<const uint8_t*>(e.data()), e.size(), reinterpret_cast<const uint8_t*>(s.data()),
-                           s.size(), context_len, true, lo, so, nullptr);
-            e.swap(lo);
-            s.swap(so);
+            HostBytes lo, so;
+            ctx->merge.run(e.data, e.size, s.data, s.size, context_len, true, lo, so, nullptr);
+            eds->size = lo.size; eds->data = lo.release();
+            seds->size = so.size; seds->data = so.release();
+            return;
         }
-        take(eds, e.size());
-        std::memcpy(eds->data, e.data(), e.size());
-        take(seds, s.size());
-        std::memcpy(seds->data, s.data(), s.size());
+        eds->size = e.size; eds->data = e.release();           // the download buffers themselves
+        seds->size = s.size; seds->data = s.release();
     });
 }
 
@@ -293,7 +287,7 @@ int edsx_vcf_transform_range(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size,
     return guarded(ctx, [&] {
         if (!eds || !seds || (!vcf && vcf_size) || (!fasta && fasta_size)) throw ParamError("null argument");
         static const uint8_t none = 0;
-        std::string e, s;
+        HostBytes e, s;
         VcfCounters c;
         VcfRange range;
         range.presorted = true; range.cur0 = cur0; range.next_start = next_start;
@@ -303,10 +297,8 @@ int edsx_vcf_transform_range(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size,
             stats->skipped_malformed = c.skipped_malformed; stats->skipped_unsupported_sv = c.skipped_unsupported_sv;
             stats->variant_groups = c.variant_groups;
         }
-        take(eds, e.size());
-        std::memcpy(eds->data, e.data(), e.size());
-        take(seds, s.size());
-        std::memcpy(seds->data, s.data(), s.size());
+        eds->size = e.size; eds->data = e.release();
+        seds->size = s.size; seds->data = s.release();
     });
 }
 

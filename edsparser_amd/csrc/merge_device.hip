@@ -625,7 +625,7 @@ bool MergePipeline::tokenize_device(const uint8_t* eds, size_t eds_n, const uint
 }
 
 void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l, bool compact,
-                        std::string& out, std::string& seds_out, hipStream_t st, MergeShard* shard)
+                        HostBytes& out, HostBytes& seds_out, hipStream_t st, MergeShard* shard)
 {
     if (l == 0) throw ParamError("context_length must be > 0 for l-EDS transformation");   // :322-324
     const bool linear = seds != nullptr;
@@ -728,8 +728,9 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     }
 
     if (n0 == 0) {                                           // empty EDS: save() prints "\n" (quirk 19)
-        out = "\n";
-        seds_out.clear();
+        out.take(1);
+        out.data[0] = '\n';
+        seds_out.take(0);
         return;
     }
     if (m >= 0xfffffff0ull) throw FormatError("EDS has too many strings for this build");
@@ -860,25 +861,29 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     if (linear) d_sout_.ensure(Q + 16);
     fp.out = d_out_.as<uint8_t>(); fp.sout = d_sout_.as<uint8_t>();
     hipLaunchKernelGGL(k_fin_write, dim3(2048), dim3(256), 0, st, fp, nstr);
-    out.resize(E + 1);
-    EDSX_HIP(hipMemcpyAsync(&out[0], d_out_.ptr, E, hipMemcpyDeviceToHost, st));
+    // malloc'ed, not value-initialised (see HostBytes): the pages are first touched by the copy
+    out.take(E + 1);
+    EDSX_HIP(hipMemcpyAsync(out.data, d_out_.ptr, E, hipMemcpyDeviceToHost, st));
     if (linear) {
-        seds_out.resize(Q + 1);
-        EDSX_HIP(hipMemcpyAsync(&seds_out[0], d_sout_.ptr, Q, hipMemcpyDeviceToHost, st));
-    } else seds_out.clear();
+        seds_out.take(Q + 1);
+        EDSX_HIP(hipMemcpyAsync(seds_out.data, d_sout_.ptr, Q, hipMemcpyDeviceToHost, st));
+    } else seds_out.take(0);
     EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
     EDSX_HIP(hipGetLastError());
     if (hctl[4]) throw FormatError("l-EDS merge nesting deeper than this build supports");
-    out[E] = '\n';                                           // eds.cpp:630
-    if (linear) seds_out[Q] = '\n';                          // eds.cpp:658
+    out.data[E] = '\n';                                      // eds.cpp:630
+    if (linear) seds_out.data[Q] = '\n';                     // eds.cpp:658
     if (shard && shard->tail_sentinel) {                     // not the last range: the text goes on
-        out.pop_back();
-        if (linear) seds_out.pop_back();
+        out.size--;
+        if (linear) seds_out.size--;
     }
     if (shard && shard->head_sentinel && shard->head_intact) {   // the left neighbour prints the shared sentinel
-        out.erase(0, (size_t)head_len + (compact ? 0 : 2));
-        if (linear) seds_out.erase(0, seds_out.find('}') + 1);
+        out.drop_front((size_t)head_len + (compact ? 0 : 2));
+        if (linear) {
+            const void* b = memchr(seds_out.data, '}', seds_out.size);
+            seds_out.drop_front(b ? static_cast<size_t>(static_cast<const uint8_t*>(b) - seds_out.data) + 1 : 0);
+        }
     }
 }
 

@@ -23,7 +23,7 @@ class MergePipeline {
 public:
     // eds/seds are host buffers (seds == nullptr => CARTESIAN); outputs end in '\n' like EDS::save.
     void run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l, bool compact,
-             std::string& out, std::string& seds_out, hipStream_t st, MergeShard* shard = nullptr);
+             HostBytes& out, HostBytes& seds_out, hipStream_t st, MergeShard* shard = nullptr);
 
     bool tokenised_on_device() const { return tokenised_on_device_; }
 

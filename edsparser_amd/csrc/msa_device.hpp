@@ -1,5 +1,8 @@
 // msa_device.hpp — host-side driver of the MSA -> EDS / l-EDS device pipeline.
 #pragma once
+#include <cstdlib>
+#include <cstring>
+#include <new>
 
 #include "dev_util.hpp"
 
@@ -29,6 +32,25 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// malloc'ed host bytes (what an edsx_buf hands to the caller); not value-initialised
+struct HostBytes {
+    uint8_t* data = nullptr;
+    size_t size = 0;
+    void take(size_t n)
+    {
+        std::free(data);
+        data = static_cast<uint8_t*>(std::malloc(n ? n : 1));
+        if (!data) throw std::bad_alloc();
+        size = n;
+    }
+    void drop_front(size_t k) { if (k > size) k = size; std::memmove(data, data + k, size - k); size -= k; }
+    uint8_t* release() { uint8_t* p = data; data = nullptr; size = 0; return p; }
+    HostBytes() = default;
+    HostBytes(const HostBytes&) = delete;
+    HostBytes& operator=(const HostBytes&) = delete;
+    ~HostBytes() { std::free(data); }
 };
 
 // device header block: geometry, counters and status, all u64

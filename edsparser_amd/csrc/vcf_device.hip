@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstring>
 #include <sstream>
+#include <chrono>
 #include <thread>
 
 namespace edsx {
@@ -761,8 +762,12 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
     if (h.bad) return false;
     // the reference's unstable std::sort (:715-718) on (pos, file index) pairs, as on the host path
     std::vector<u32> order(nr);
+    const auto ts0 = std::chrono::steady_clock::now();
     if (presorted) for (u64 i = 0; i < nr; i++) order[i] = (u32)i;
     else vcf_sort_order(hpos.data(), nr, order.data());
+    { const char* e = getenv("EDSX_TRACE");
+      if (e && atoi(e)) fprintf(stderr, "[edsx vcf]   std::sort of %llu positions %8.3f ms\n", (unsigned long long)nr,
+                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count()); }
     vt_order_.ensure(4 * (nr + 1));
     EDSX_HIP(hipMemcpyAsync(vt_order_.ptr, order.data(), 4 * nr, hipMemcpyHostToDevice, st));
     h.n = nr;
@@ -787,9 +792,18 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
     return true;
 }
 
-void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, std::string& eds,
-                      std::string& seds, VcfCounters& stats, hipStream_t st, const VcfRange& range)
+void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, HostBytes& eds,
+                      HostBytes& seds, VcfCounters& stats, hipStream_t st, const VcfRange& range)
 {
+    // EDSX_TRACE=1: wall-clock of the host-visible stages on stderr (every mark follows a stream synchronisation)
+    static const bool trace = [] { const char* e = getenv("EDSX_TRACE"); return e && atoi(e); }();
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[edsx vcf] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     stats = VcfCounters();
     // ---- FASTA metadata (:51-86)
     u64 seq_start, lw, seq_size;
@@ -803,12 +817,17 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
         if (!next_line(fasta, fasta_n, pos, line)) throw FormatError("FASTA file is empty");
         lw = line.size();
         seq_size = line.size();
-        while (next_line(fasta, fasta_n, pos, line)) {
-            if (line.empty()) continue;
-            if (line[0] == '>') break;
-            seq_size += line.size();
+        while (pos < fasta_n) {                                // the remaining lines: lengths only, no copies
+            const uint8_t* nl = static_cast<const uint8_t*>(memchr(fasta + pos, '\n', fasta_n - pos));
+            const size_t end = nl ? static_cast<size_t>(nl - fasta) : fasta_n;
+            if (end > pos) {
+                if (fasta[pos] == '>') break;
+                seq_size += end - pos;
+            }
+            pos = nl ? end + 1 : fasta_n;
         }
     }
+    mark("fasta metadata");
     // ---- VCF records (:690-712) and the unstable sort (:715-718)
     std::vector<VcfPart> parts;
     std::vector<u64> part_base;                              // first global record index of every part
@@ -816,9 +835,11 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     u64 dev_nrec = 0, dev_max_samples = 0;
     const bool on_device = tokenize_device(vcf, vcf_n, range.presorted, st, dev_nrec, dev_max_samples, stats);
     tokenised_on_device_ = on_device;
+    mark(on_device ? "device tokenise" : "device tokenise attempt");
     if (!on_device) {
         stats = VcfCounters();
         tokenise(vcf, vcf_n, parts, part_base, stats, false);
+        mark("host tokenise");
     }
     if (!on_device) {
         const unsigned nt = (unsigned)parts.size();
@@ -867,6 +888,7 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
     const u64 refc_n = nblk ? hctl[1] : 0;
+    mark("fasta upload + compaction");
 
     VcfDev d{};
     d.fasta = d_fasta_.as<uint8_t>(); d.fasta_n = fasta_n; d.seq_start = seq_start; d.seq_size = seq_size; d.lw = lw;
@@ -1003,6 +1025,7 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
         EDSX_HIP(hipMemcpyAsync(&last_cur, g_cur_.as<u64>() + (ngrp - 1), 8, hipMemcpyDeviceToHost, st));
         EDSX_HIP(hipStreamSynchronize(st));
         E = hctl[7]; Q = hctl[8]; cur = last_cur;
+        mark("groups, haplotypes, sizes");
     }
     // ---- tail (:658-665)
     // A position range that is not the last one ends with what the reference flushes in front of the next
@@ -1027,13 +1050,17 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     }
     if (tail)
         hipLaunchKernelGGL(k_tail, dim3(1024), dim3(256), 0, st, d, cur, tail, d_eds_.as<uint8_t>() + E, d_seds_.as<uint8_t>() + Q);
-    eds.resize(Etot);
-    seds.resize(Qtot);
-    if (Etot) EDSX_HIP(hipMemcpyAsync(&eds[0], d_eds_.ptr, Etot, hipMemcpyDeviceToHost, st));
-    if (Qtot) EDSX_HIP(hipMemcpyAsync(&seds[0], d_seds_.ptr, Qtot, hipMemcpyDeviceToHost, st));
+    mark("tail");
+    // malloc'ed, not value-initialised: the pages are first touched by the copy itself (a zero-filling
+    // std::string::resize costs as much as the whole device part for a 134 MB output)
+    eds.take(Etot);
+    seds.take(Qtot);
+    if (Etot) EDSX_HIP(hipMemcpyAsync(eds.data, d_eds_.ptr, Etot, hipMemcpyDeviceToHost, st));
+    if (Qtot) EDSX_HIP(hipMemcpyAsync(seds.data, d_seds_.ptr, Qtot, hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
     EDSX_HIP(hipGetLastError());
     stats.variant_groups = ngrp;                             // :724-726
+    mark("emit + download");
 }
 
 } // namespace edsx

@@ -3,6 +3,8 @@
 
 #include "msa_device.hpp"
 
+#include <cstdlib>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -30,7 +32,7 @@ void vcf_sort_order(const u64* pos, size_t n, u32* order_out);
 class VcfPipeline {
 public:
     // host buffers in; eds/seds text out (FULL brackets, no trailing newline, like the reference)
-    void run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, std::string& eds, std::string& seds,
+    void run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, HostBytes& eds, HostBytes& seds,
              VcfCounters& stats, hipStream_t st, const VcfRange& range = VcfRange());
 
     bool tokenised_on_device() const { return tokenised_on_device_; }
