@@ -9,7 +9,8 @@
 // touches each symbol once and strings are materialised once, at the end.
 //
 // Data layout in HBM
-//   chars/str_off     all original strings back to back (host tokeniser, eds.cpp:39-155 rules)
+//   chars/str_off     all original strings back to back (device tokeniser k_tok_*, host tokenisers for odd
+//                     text; eds.cpp:39-155 rules)
 //   entry pool        one entry per string of every symbol that ever existed: leaves are the
 //                     original strings; an entry made by a merge points to its (left, right)
 //                     parents, carries its length and, for LINEAR, its source set as a bitset of

@@ -1,7 +1,8 @@
 // vcf_device.hip — VCF (+ reference FASTA) -> EDS / sEDS on gfx950: the variant-overlay walk.
 //
-// Host (this file, C++): FASTA metadata, VCF tokeniser, std::sort by POS — the text-parsing front
-// end of src/cpp/lib/transforms/vcf_transforms.cpp (:51-86, :142-326, :715-718).
+// Host (this file, C++): FASTA metadata, std::sort by POS, and the VCF tokeniser for files the device
+// tokeniser does not accept — the text-parsing front end of src/cpp/lib/transforms/vcf_transforms.cpp
+// (:51-86, :142-326, :715-718).  Plain files are tokenised on the device (k_vt_*).
 // Device (HIP kernels): everything from the sorted records on —
 //   group_overlapping_variants :482-534   -> max-scan of the record ends + k_mark_groups
 //   read_fasta_region :98-129             -> k_fa_count/k_fa_compact (newline-free reference stream)
