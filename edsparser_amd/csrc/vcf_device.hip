@@ -99,6 +99,25 @@ __global__ void k_fa_compact(const uint8_t* __restrict__ f, u64 n, u64 seq_start
     }
 }
 
+// seq_size of parse_fasta_metadata (:69-84) on the device: the record ends at the first later line that starts with
+// '>' (or at EOF); its size is the number of bytes that are not '\n' from the first sequence line on ('\r' counts,
+// as in the reference's getline loop).
+__global__ void k_fa_record_end(const uint8_t* __restrict__ f, u64 n, u64 from, u64* __restrict__ rec_end)
+{
+    u64 best = ~0ull;
+    for (u64 i = from + blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (f[i] == '>' && f[i - 1] == '\n') { best = i; break; }
+    if (best != ~0ull) atomicMin((unsigned long long*)rec_end, (unsigned long long)best);
+}
+__global__ void k_fa_seq_bytes(const uint8_t* __restrict__ f, u64 from, const u64* __restrict__ rec_end, u64* __restrict__ count)
+{
+    const u64 hi = *rec_end;
+    u64 c = 0;
+    for (u64 i = from + blockIdx.x * (u64)blockDim.x + threadIdx.x; i < hi; i += (u64)gridDim.x * blockDim.x) c += f[i] != '\n';
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd((unsigned long long*)count, (unsigned long long)c);
+}
+
 // ---- grouping -------------------------------------------------------------------------------------
 __global__ void k_rec_ends(const u64* __restrict__ start, const u64* __restrict__ reflen, u64 n, u64* __restrict__ ends)
 {
@@ -299,23 +318,32 @@ __global__ void k_grp_common(VcfDev d, GrpArrays a)
 
 struct EmitArrays { const u64* eds_off; const u64* seds_off; uint8_t* eds; uint8_t* seds; };
 
-// one wave per group: common region copy (lanes = bytes), then the group symbol
-__global__ void __launch_bounds__(256) k_grp_emit(VcfDev d, GrpArrays a, HapArrays h, EmitArrays e)
+// common text in front of every group: one wave per group, lanes = bytes (the bandwidth part of the output)
+__global__ void __launch_bounds__(256) k_grp_emit_common(VcfDev d, GrpArrays a, EmitArrays e)
 {
     const u32 lane = threadIdx.x & 63;
     const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 g = wave; g < d.ngrp; g += nw) {
+        const u64 clen = a.commonlen[g];
+        if (!clen) continue;
+        uint8_t* eo = e.eds + e.eds_off[g];
+        uint8_t* so = e.seds + e.seds_off[g];
+        const u64 cur = g ? a.cur_after[g - 1] : d.cur0;
+        const u64 c0 = fa_cpos(d, d.seq_start + cur + cur / d.lw);
+        if (lane == 0) { eo[0] = '{'; eo[clen + 1] = '}'; so[0] = '{'; so[1] = '0'; so[2] = '}'; }
+        for (u64 i = lane; i < clen; i += 64) eo[1 + i] = d.refc[c0 + i];
+    }
+}
+
+// the group symbols: short texts behind a chain of dependent loads, so one THREAD per group — a million independent
+// chains in flight hide the latency that one lane per wave could not (3.7 ms -> see DESIGN section 5)
+__global__ void __launch_bounds__(256) k_grp_emit(VcfDev d, GrpArrays a, HapArrays h, EmitArrays e)
+{
+    for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < d.ngrp; g += (u64)gridDim.x * blockDim.x) {
         uint8_t* eo = e.eds + e.eds_off[g];
         uint8_t* so = e.seds + e.seds_off[g];
         const u64 clen = a.commonlen[g];
-        if (clen) {
-            const u64 cur = g ? a.cur_after[g - 1] : d.cur0;
-            const u64 c0 = fa_cpos(d, d.seq_start + cur + cur / d.lw);
-            if (lane == 0) { eo[0] = '{'; eo[clen + 1] = '}'; so[0] = '{'; so[1] = '0'; so[2] = '}'; }
-            for (u64 i = lane; i < clen; i += 64) eo[1 + i] = d.refc[c0 + i];
-            eo += clen + 2; so += 3;
-        }
-        if (lane != 0) continue;                               // the symbol itself is short: one lane
+        if (clen) { eo += clen + 2; so += 3; }
         const u64 r0 = d.grp_r0[g];
         const u64 h0 = h.raw0[g];
         const u64 nsamp = d.pair0[r0 + 1] - d.pair0[r0];
@@ -325,9 +353,16 @@ __global__ void __launch_bounds__(256) k_grp_emit(VcfDev d, GrpArrays a, HapArra
         for (u64 x = 0; x < a.nraw[g]; x++) {
             const u32 c = h.canon[h0 + x];
             if (c & 0x80000000u) continue;
+            // carriers of this haplotype: one load per 64 samples (a per-sample load could not be kept in a register
+            // across the byte stores below, which may alias it as far as the compiler knows)
+            const u64* bw = bits + (u64)c * h.sw;
+            const u32 nw = (u32)((nsamp + 63) >> 6);
             u64 cnt = 0;
             if (nsamp) {
-                for (u64 s = 0; s < nsamp; s++) cnt += bits[(u64)c * h.sw + (s >> 6)] >> (s & 63) & 1;
+                for (u32 w = 0; w < nw; w++) {
+                    const u64 rem = nsamp - 64ull * w;
+                    cnt += __builtin_popcountll(bw[w] & (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)));
+                }
                 if (!cnt) continue;
             }
             if (!first) *eo++ = ',';
@@ -336,13 +371,17 @@ __global__ void __launch_bounds__(256) k_grp_emit(VcfDev d, GrpArrays a, HapArra
             for (u64 i = 0; i < h.rawlen[h0 + x]; i++) *eo++ = src[i];
             if (nsamp) {
                 *so++ = '{';
-                for (u64 s = 0; s < nsamp; s++) {
-                    if (!(bits[(u64)c * h.sw + (s >> 6)] >> (s & 63) & 1)) continue;
-                    u32 id = (u32)s + 1, nd = ndigits(id);
-                    u32 xx = id;
-                    for (int dd = (int)nd - 1; dd >= 0; dd--) { so[dd] = (uint8_t)('0' + xx % 10); xx /= 10; }
-                    so += nd;
-                    *so++ = ',';
+                for (u32 w = 0; w < nw; w++) {
+                    const u64 rem = nsamp - 64ull * w;
+                    u64 v = bw[w] & (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull));
+                    while (v) {
+                        const u32 id = w * 64u + (u32)__builtin_ctzll(v) + 1u, nd = ndigits(id);
+                        v &= v - 1;
+                        u32 xx = id;
+                        for (int dd = (int)nd - 1; dd >= 0; dd--) { so[dd] = (uint8_t)('0' + xx % 10); xx /= 10; }
+                        so += nd;
+                        *so++ = ',';
+                    }
                 }
                 so[-1] = '}';
             }
@@ -807,7 +846,7 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     };
     stats = VcfCounters();
     // ---- FASTA metadata (:51-86)
-    u64 seq_start, lw, seq_size;
+    u64 seq_start, lw, seq_size, rest_from = 0;
     {
         size_t pos = 0;
         std::string line;
@@ -817,16 +856,8 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
         seq_start = eof ? fasta_n : pos;
         if (!next_line(fasta, fasta_n, pos, line)) throw FormatError("FASTA file is empty");
         lw = line.size();
-        seq_size = line.size();
-        while (pos < fasta_n) {                                // the remaining lines: lengths only, no copies
-            const uint8_t* nl = static_cast<const uint8_t*>(memchr(fasta + pos, '\n', fasta_n - pos));
-            const size_t end = nl ? static_cast<size_t>(nl - fasta) : fasta_n;
-            if (end > pos) {
-                if (fasta[pos] == '>') break;
-                seq_size += end - pos;
-            }
-            pos = nl ? end + 1 : fasta_n;
-        }
+        seq_size = line.size();                                // + the later lines, counted on the device (below)
+        rest_from = pos;
     }
     mark("fasta metadata");
     // ---- VCF records (:690-712) and the unstable sort (:715-718)
@@ -878,7 +909,12 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     refc_.ensure(body + 16);
     u64 hctl[32] = {0};
     hctl[0] = nblk; hctl[10] = ~0ull;
+    hctl[12] = fasta_n;                                      // record end (atomicMin), [13] bytes of the later lines
     EDSX_HIP(hipMemcpyAsync(ctl, hctl, sizeof(hctl), hipMemcpyHostToDevice, st));
+    if (rest_from < fasta_n) {
+        hipLaunchKernelGGL(k_fa_record_end, dim3(1024), dim3(256), 0, st, d_fasta_.as<uint8_t>(), (u64)fasta_n, rest_from, ctl + 12);
+        hipLaunchKernelGGL(k_fa_seq_bytes, dim3(1024), dim3(256), 0, st, d_fasta_.as<uint8_t>(), rest_from, ctl + 12, ctl + 13);
+    }
     if (nblk) {
         hipLaunchKernelGGL(k_fa_count, dim3(1024), dim3(256), 0, st, d_fasta_.as<uint8_t>(), (u64)fasta_n, seq_start,
                            blkpre_.as<u64>(), nblk);
@@ -889,7 +925,8 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
     const u64 refc_n = nblk ? hctl[1] : 0;
-    mark("fasta upload + compaction");
+    seq_size += hctl[13];
+    mark("fasta upload, metadata, compaction");
 
     VcfDev d{};
     d.fasta = d_fasta_.as<uint8_t>(); d.fasta_n = fasta_n; d.seq_start = seq_start; d.seq_size = seq_size; d.lw = lw;
@@ -1047,6 +1084,7 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     d_eds_.ensure(Etot + 16); d_seds_.ensure(Qtot + 16);
     if (ngrp) {
         EmitArrays ea{g_eds_.as<u64>(), g_seds_.as<u64>(), d_eds_.as<uint8_t>(), d_seds_.as<uint8_t>()};
+        hipLaunchKernelGGL(k_grp_emit_common, dim3(2048), dim3(256), 0, st, d, ga, ea);
         hipLaunchKernelGGL(k_grp_emit, dim3(2048), dim3(256), 0, st, d, ga, ha, ea);
     }
     if (tail)
