@@ -519,12 +519,20 @@ __global__ void k_vt_count(const uint8_t* __restrict__ raw, u64 n, const u64* __
     if (bad) ctl->bad = 1;
     if (mx) atomicMax((unsigned long long*)&ctl->max_samples, (unsigned long long)mx);
 }
+// strictly ascending positions: the reference's std::sort leaves such an array as it is (no two keys compare equal,
+// so its result is THE sorted order) and the host sort, with its two PCIe trips, is skipped
+__global__ void k_vt_ascending(const u64* __restrict__ pos, u64 nrec, VtCtl* ctl)
+{
+    bool un = false;
+    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j + 1 < nrec; j += (u64)gridDim.x * blockDim.x) un |= pos[j] >= pos[j + 1];
+    if (un) ctl->t_alt = 1;                                      // scratch until the offset scans overwrite it
+}
 // counts in sorted order (inputs of the four offset scans)
 __global__ void k_vt_gather(VtRec r, const u32* __restrict__ order, u64 nrec, u64* __restrict__ a, u64* __restrict__ b,
                             u64* __restrict__ c, u64* __restrict__ d)
 {
     for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < nrec; j += (u64)gridDim.x * blockDim.x) {
-        const u64 i = order[j];
+        const u64 i = order ? order[j] : j;
         a[j] = r.nalt[i]; b[j] = r.altc[i]; c[j] = r.ngt[i]; d[j] = r.nall[i];
     }
 }
@@ -534,7 +542,7 @@ __global__ void k_vt_fill(const uint8_t* __restrict__ raw, u64 n, const u64* __r
                           u64 nrec, VtOut o, const VtCtl* ctl)
 {
     for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < nrec; j += (u64)gridDim.x * blockDim.x) {
-        const u64 lo = lstart[order[j]];
+        const u64 lo = lstart[order ? order[j] : j];
         VtCounts c;
         VtSink k{o.altoff + o.alt0[j], o.altc0[j], o.altchars, o.pa0 + o.pair0[j], o.gtc0[j], o.alleles};
         vt_parse<true>(raw, lo, vt_line_end(raw, lo, n), c, k);
@@ -795,24 +803,30 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
     for (DevBuf* b : {&vt_pos_, &vt_reflen_, &vt_nalt_, &vt_altc_, &vt_ngt_, &vt_nall_, &vt_s1_, &vt_s2_, &vt_s3_, &vt_s4_}) b->ensure(8 * (nr + 2));
     VtRec rec{vt_pos_.as<u64>(), vt_reflen_.as<u64>(), vt_nalt_.as<u64>(), vt_altc_.as<u64>(), vt_ngt_.as<u64>(), vt_nall_.as<u64>()};
     hipLaunchKernelGGL(k_vt_count, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_lstart_.as<u64>(), nr, rec, ctl);
-    std::vector<u64> hpos(nr);
-    EDSX_HIP(hipMemcpyAsync(hpos.data(), vt_pos_.ptr, 8 * nr, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_vt_ascending, dim3(1024), dim3(256), 0, st, vt_pos_.as<u64>(), nr, ctl);
     EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
     if (h.bad) return false;
-    // the reference's unstable std::sort (:715-718) on (pos, file index) pairs, as on the host path
-    std::vector<u32> order(nr);
-    const auto ts0 = std::chrono::steady_clock::now();
-    if (presorted) for (u64 i = 0; i < nr; i++) order[i] = (u32)i;
-    else vcf_sort_order(hpos.data(), nr, order.data());
-    { const char* e = getenv("EDSX_TRACE");
-      if (e && atoi(e)) fprintf(stderr, "[edsx vcf]   std::sort of %llu positions %8.3f ms\n", (unsigned long long)nr,
-                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count()); }
-    vt_order_.ensure(4 * (nr + 1));
-    EDSX_HIP(hipMemcpyAsync(vt_order_.ptr, order.data(), 4 * nr, hipMemcpyHostToDevice, st));
+    // The reference's unstable std::sort (:715-718) on (pos, file index) pairs, as on the host path — unless the
+    // positions already ascend strictly (the usual VCF) or the caller hands the records over in final order.
+    const u32* d_order = nullptr;
+    std::vector<u32> order;
+    if (!presorted && h.t_alt) {
+        std::vector<u64> hpos(nr);
+        EDSX_HIP(hipMemcpy(hpos.data(), vt_pos_.ptr, 8 * nr, hipMemcpyDeviceToHost));
+        order.resize(nr);
+        const auto ts0 = std::chrono::steady_clock::now();
+        vcf_sort_order(hpos.data(), nr, order.data());
+        { const char* e = getenv("EDSX_TRACE");
+          if (e && atoi(e)) fprintf(stderr, "[edsx vcf]   std::sort of %llu positions %8.3f ms\n", (unsigned long long)nr,
+                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count()); }
+        vt_order_.ensure(4 * (nr + 1));
+        EDSX_HIP(hipMemcpyAsync(vt_order_.ptr, order.data(), 4 * nr, hipMemcpyHostToDevice, st));
+        d_order = vt_order_.as<u32>();
+    }
     h.n = nr;
     EDSX_HIP(hipMemcpyAsync(&ctl->n, &h.n, 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_vt_gather, dim3(2048), dim3(256), 0, st, rec, vt_order_.as<u32>(), nr, vt_s1_.as<u64>(), vt_s2_.as<u64>(),
+    hipLaunchKernelGGL(k_vt_gather, dim3(2048), dim3(256), 0, st, rec, d_order, nr, vt_s1_.as<u64>(), vt_s2_.as<u64>(),
                        vt_s3_.as<u64>(), vt_s4_.as<u64>());
     alt0_.ensure(8 * (nr + 2)); pair0_.ensure(8 * (nr + 2)); start_.ensure(8 * (nr + 2)); reflen_.ensure(8 * (nr + 2));
     exclusive_scan_u64(vt_s1_.as<u64>(), alt0_.as<u64>(), &ctl->n, &ctl->t_alt, scan_tmp_.as<u64>(), st);
@@ -824,7 +838,7 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
     altoff_.ensure(8 * (h.t_alt + 2)); altchars_.ensure(h.t_altc + 16); pa0_.ensure(8 * (h.t_pair + 2)); alleles_.ensure(4 * (h.t_all + 4));
     VtOut o{start_.as<u64>(), reflen_.as<u64>(), alt0_.as<u64>(), altoff_.as<u64>(), altchars_.as<uint8_t>(), pair0_.as<u64>(),
             pa0_.as<u64>(), alleles_.as<int>(), vt_s2_.as<u64>(), vt_s4_.as<u64>()};
-    hipLaunchKernelGGL(k_vt_fill, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_lstart_.as<u64>(), vt_order_.as<u32>(), nr, o, ctl);
+    hipLaunchKernelGGL(k_vt_fill, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_lstart_.as<u64>(), d_order, nr, o, ctl);
     EDSX_HIP(hipStreamSynchronize(st));
     EDSX_HIP(hipGetLastError());
     nrec = nr;
