@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import edsparser_amd  # noqa: E402
 from merge_cases import genrandomeds_shaped  # noqa: E402
-from measure_sharded_paths import gen_vcf  # noqa: E402  (module runs its main() only as a script)
+from vcf_cases import gen_vcf  # noqa: E402
 
 ctx = edsparser_amd.Context(0)
 eds, seds = genrandomeds_shaped(10, 0.10, 42)
