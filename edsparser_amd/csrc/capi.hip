@@ -260,7 +260,8 @@ int edsx_vcf_index(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size, edsx_buf*
         static const uint8_t none = 0;
         std::vector<u64> p, r, lo, ll;
         VcfCounters c;
-        vcf_index(vcf ? vcf : &none, vcf_size, p, r, lo, ll, c);
+        if (!ctx->vcf.index_device(vcf ? vcf : &none, vcf_size, nullptr, p, r, lo, ll, c))   // plain text: on the GPU
+            vcf_index(vcf ? vcf : &none, vcf_size, p, r, lo, ll, c);
         if (stats) {
             stats->total_variants = c.total_variants; stats->processed_variants = c.processed_variants;
             stats->skipped_malformed = c.skipped_malformed; stats->skipped_unsupported_sv = c.skipped_unsupported_sv;

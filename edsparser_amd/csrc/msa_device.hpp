@@ -1,6 +1,8 @@
 // msa_device.hpp — host-side driver of the MSA -> EDS / l-EDS device pipeline.
 #pragma once
 #include <cstdlib>
+#include <thread>
+#include <vector>
 #include <cstring>
 #include <new>
 

@@ -503,16 +503,17 @@ __device__ __forceinline__ u64 vt_line_end(const uint8_t* raw, u64 lo, u64 n)
     while (hi < n && raw[hi] != '\n') hi++;
     return hi;
 }
-struct VtRec { u64* pos; u64* reflen; u64* nalt; u64* altc; u64* ngt; u64* nall; };
+struct VtRec { u64* pos; u64* reflen; u64* nalt; u64* altc; u64* ngt; u64* nall; u64* linelen; /* may be null */ };
 __global__ void k_vt_count(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ lstart, u64 nrec, VtRec r, VtCtl* ctl)
 {
     bool bad = false;
     u64 mx = 0;
     for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < nrec; j += (u64)gridDim.x * blockDim.x) {
-        const u64 lo = lstart[j];
+        const u64 lo = lstart[j], hi = vt_line_end(raw, lo, n);
         VtCounts c;
-        if (!vt_parse<false>(raw, lo, vt_line_end(raw, lo, n), c, VtSink{})) bad = true;
-        if (c.pos == 0 || c.pos - 1 + c.reflen < c.pos - 1) bad = true;      // wrapped positions: host sweep (see run)
+        if (!vt_parse<false>(raw, lo, hi, c, VtSink{})) bad = true;
+        if (r.linelen) r.linelen[j] = hi - lo;                               // index pass of a partitioned run
+        else if (c.pos == 0 || c.pos - 1 + c.reflen < c.pos - 1) bad = true; // wrapped positions: host sweep (see run)
         r.pos[j] = c.pos; r.reflen[j] = c.reflen; r.nalt[j] = c.nalt; r.altc[j] = c.altc; r.ngt[j] = c.ngt; r.nall[j] = c.nall;
         mx = c.ngt > mx ? c.ngt : mx;
     }
@@ -801,7 +802,7 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
     vt_lstart_.ensure(8 * (nr + 1));
     hipLaunchKernelGGL(k_vt_scatter, dim3(2048), dim3(256), 0, st, vt_flag_.as<u64>(), vt_idx_.as<u64>(), (u64)n, vt_lstart_.as<u64>());
     for (DevBuf* b : {&vt_pos_, &vt_reflen_, &vt_nalt_, &vt_altc_, &vt_ngt_, &vt_nall_, &vt_s1_, &vt_s2_, &vt_s3_, &vt_s4_}) b->ensure(8 * (nr + 2));
-    VtRec rec{vt_pos_.as<u64>(), vt_reflen_.as<u64>(), vt_nalt_.as<u64>(), vt_altc_.as<u64>(), vt_ngt_.as<u64>(), vt_nall_.as<u64>()};
+    VtRec rec{vt_pos_.as<u64>(), vt_reflen_.as<u64>(), vt_nalt_.as<u64>(), vt_altc_.as<u64>(), vt_ngt_.as<u64>(), vt_nall_.as<u64>(), nullptr};
     hipLaunchKernelGGL(k_vt_count, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_lstart_.as<u64>(), nr, rec, ctl);
     hipLaunchKernelGGL(k_vt_ascending, dim3(1024), dim3(256), 0, st, vt_pos_.as<u64>(), nr, ctl);
     EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -844,6 +845,50 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
     nrec = nr;
     max_samples = h.max_samples;
     return true;
+}
+
+// Index pass of a partitioned run on the device: the first half of tokenize_device (line starts, count pass) with the
+// line lengths kept.  false: not a plain file, the host index pass takes it (wrapped positions are fine here: the
+// planner decides what to do with them).
+bool VcfPipeline::index_device(const uint8_t* vcf, size_t n, hipStream_t st, std::vector<u64>& pos, std::vector<u64>& reflen,
+                               std::vector<u64>& line_off, std::vector<u64>& line_len, VcfCounters& stats)
+{
+    { const char* e = getenv("EDSX_HOST_TOKENIZER"); if (e && atoi(e)) return false; }
+    if (n == 0) return false;
+    vt_raw_.ensure(n + 16);
+    vt_flag_.ensure(8 * (n + 2)); vt_idx_.ensure(8 * (n + 2));
+    scan_tmp_.ensure(8 * ((n + 2) / SCAN_TILE + 4));
+    ctl_.ensure(8 * 32);
+    VtCtl* ctl = reinterpret_cast<VtCtl*>(ctl_.as<u64>() + 16);
+    VtCtl h{};
+    h.n = n;
+    EDSX_HIP(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    EDSX_HIP(hipMemcpyAsync(vt_raw_.ptr, vcf, n, hipMemcpyHostToDevice, st));
+    const uint8_t* raw = vt_raw_.as<uint8_t>();
+    hipLaunchKernelGGL(k_vt_lines, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_flag_.as<u64>(), ctl);
+    exclusive_scan_u64(vt_flag_.as<u64>(), vt_idx_.as<u64>(), &ctl->n, &ctl->nrec, scan_tmp_.as<u64>(), st);
+    EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    if (h.bad || h.nrec >= 0xffffffffull) return false;
+    const u64 nr = h.nrec;
+    stats = VcfCounters();
+    stats.total_variants = stats.processed_variants = nr;
+    pos.assign(nr, 0); reflen.assign(nr, 0); line_off.assign(nr, 0); line_len.assign(nr, 0);
+    if (nr == 0) return true;
+    vt_lstart_.ensure(8 * (nr + 1));
+    hipLaunchKernelGGL(k_vt_scatter, dim3(2048), dim3(256), 0, st, vt_flag_.as<u64>(), vt_idx_.as<u64>(), (u64)n, vt_lstart_.as<u64>());
+    for (DevBuf* b : {&vt_pos_, &vt_reflen_, &vt_nalt_, &vt_altc_, &vt_ngt_, &vt_nall_, &vt_s1_}) b->ensure(8 * (nr + 2));
+    VtRec rec{vt_pos_.as<u64>(), vt_reflen_.as<u64>(), vt_nalt_.as<u64>(), vt_altc_.as<u64>(), vt_ngt_.as<u64>(), vt_nall_.as<u64>(),
+              vt_s1_.as<u64>()};
+    hipLaunchKernelGGL(k_vt_count, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_lstart_.as<u64>(), nr, rec, ctl);
+    EDSX_HIP(hipMemcpyAsync(pos.data(), vt_pos_.ptr, 8 * nr, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(reflen.data(), vt_reflen_.ptr, 8 * nr, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(line_off.data(), vt_lstart_.ptr, 8 * nr, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(line_len.data(), vt_s1_.ptr, 8 * nr, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    EDSX_HIP(hipGetLastError());
+    return !h.bad;
 }
 
 void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, size_t fasta_n, HostBytes& eds,

@@ -36,6 +36,8 @@ public:
              VcfCounters& stats, hipStream_t st, const VcfRange& range = VcfRange());
 
     bool tokenised_on_device() const { return tokenised_on_device_; }
+    bool index_device(const uint8_t* vcf, size_t n, hipStream_t st, std::vector<u64>& pos, std::vector<u64>& reflen,
+                      std::vector<u64>& line_off, std::vector<u64>& line_len, VcfCounters& stats);
 
 private:
     bool tokenised_on_device_ = false;

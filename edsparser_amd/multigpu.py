@@ -311,7 +311,10 @@ class VcfSharder:
         base = np.concatenate(([0], np.cumsum([len(g[0]) for g in gathered]))).astype(np.int64)
         gpos = np.concatenate([g[0] for g in gathered]).astype(np.uint64)
         greflen = np.concatenate([g[1] for g in gathered]).astype(np.uint64)
-        order = self.sort_fn(gpos).astype(np.int64)
+        if len(gpos) < 2 or bool(np.all(gpos[1:] > gpos[:-1])):
+            order = np.arange(len(gpos), dtype=np.int64)           # strictly ascending: the sort cannot move anything
+        else:
+            order = self.sort_fn(gpos).astype(np.int64)
         cuts, start, wraps = plan_vcf_cuts(gpos, greflen, order, world)
         # lines of mine that another rank's range needs, and the runs I keep
         outgoing = {}
