@@ -43,8 +43,7 @@ template <class F> int guarded(edsx_ctx* ctx, F&& f)
 
 void take(edsx_buf* b, size_t n)
 {
-    b->data = static_cast<uint8_t*>(malloc(n ? n : 1));
-    if (!b->data) throw std::bad_alloc();
+    b->data = HostBytes::alloc(n);
     b->size = n;
 }
 

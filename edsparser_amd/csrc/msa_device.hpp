@@ -1,6 +1,7 @@
 // msa_device.hpp — host-side driver of the MSA -> EDS / l-EDS device pipeline.
 #pragma once
 #include <cstdlib>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 #include <cstring>
@@ -43,9 +44,23 @@ struct HostBytes {
     void take(size_t n)
     {
         std::free(data);
-        data = static_cast<uint8_t*>(std::malloc(n ? n : 1));
-        if (!data) throw std::bad_alloc();
+        data = alloc(n);
         size = n;
+    }
+    // Large outputs: 2 MB-aligned and advised for transparent huge pages, so that the first touch of a GB of fresh
+    // memory (by the device-to-host copy) is a few hundred page faults instead of a few hundred thousand.  Still
+    // released with free().
+    static uint8_t* alloc(size_t n)
+    {
+        void* p = nullptr;
+        if (n >= ((size_t)8 << 20)) {
+            const size_t huge = (size_t)2 << 20, len = (n + huge - 1) & ~(huge - 1);
+            if (posix_memalign(&p, huge, len) == 0 && p) { (void)madvise(p, len, MADV_HUGEPAGE); return static_cast<uint8_t*>(p); }
+            p = nullptr;
+        }
+        p = std::malloc(n ? n : 1);
+        if (!p) throw std::bad_alloc();
+        return static_cast<uint8_t*>(p);
     }
     void drop_front(size_t k) { if (k > size) k = size; std::memmove(data, data + k, size - k); size -= k; }
     uint8_t* release() { uint8_t* p = data; data = nullptr; size = 0; return p; }
