@@ -157,9 +157,8 @@ int edsx_msa_transform(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint3
         ctx->msa.emit(ctx->d_eds.as<uint8_t>(), ctx->d_seds.as<uint8_t>(), st);
         take(eds, E);
         take(seds, Q);
-        EDSX_HIP(hipMemcpyAsync(eds->data, ctx->d_eds.ptr, E, hipMemcpyDeviceToHost, st));
-        EDSX_HIP(hipMemcpyAsync(seds->data, ctx->d_seds.ptr, Q, hipMemcpyDeviceToHost, st));
-        EDSX_HIP(hipStreamSynchronize(st));
+        PinnedDownload::copy(eds->data, ctx->d_eds.ptr, E, st);
+        PinnedDownload::copy(seds->data, ctx->d_seds.ptr, Q, st);
     });
 }
 

@@ -4,8 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 namespace edsx {
 
@@ -20,6 +24,68 @@ struct DeviceError : std::runtime_error { using std::runtime_error::runtime_erro
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+
+// ---- large device-to-host copies ----------------------------------------------------------------------
+// hipMemcpy into pageable memory is copied out of the runtime's staging buffer by ONE host thread (≈18 GB/s into
+// huge-page-backed memory on this stack), well under what the link gives a pinned destination.  Outputs of this
+// engine are GB-sized text, so large downloads go through two pinned staging chunks: the DMA of chunk i+1 overlaps
+// the copy of chunk i into the caller's buffer by several host threads.  Synchronous: returns when dst is complete.
+class PinnedDownload {
+public:
+    static void copy(void* dst, const void* dev_src, size_t n, hipStream_t st)
+    {
+        if (n < MIN_BYTES) {
+            if (n) EDSX_HIP(hipMemcpyAsync(dst, dev_src, n, hipMemcpyDeviceToHost, st));
+            EDSX_HIP(hipStreamSynchronize(st));
+            return;
+        }
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);                  // one set of staging buffers per process
+        static Stage sg;
+        sg.ensure();
+        uint8_t* out = static_cast<uint8_t*>(dst);
+        const uint8_t* src = static_cast<const uint8_t*>(dev_src);
+        const size_t nchunks = (n + CHUNK - 1) / CHUNK;
+        auto issue = [&](size_t i) {
+            const size_t off = i * CHUNK, len = std::min(CHUNK, n - off);
+            EDSX_HIP(hipMemcpyAsync(sg.pin[i & 1], src + off, len, hipMemcpyDeviceToHost, st));
+            EDSX_HIP(hipEventRecord(sg.ev[i & 1], st));
+        };
+        issue(0);
+        for (size_t i = 0; i < nchunks; i++) {
+            if (i + 1 < nchunks) issue(i + 1);
+            EDSX_HIP(hipEventSynchronize(sg.ev[i & 1]));
+            const size_t off = i * CHUNK, len = std::min(CHUNK, n - off);
+            const uint8_t* from = sg.pin[i & 1];
+            std::thread th[THREADS - 1];
+            const size_t part = ((len + THREADS - 1) / THREADS + 63) & ~(size_t)63;     // THREADS * part >= len
+            for (unsigned t = 1; t < THREADS; t++) {
+                const size_t lo = std::min(len, part * t), hi = std::min(len, part * (t + 1));
+                th[t - 1] = std::thread([=] { if (hi > lo) std::memcpy(out + off + lo, from + lo, hi - lo); });
+            }
+            std::memcpy(out + off, from, std::min(len, part));
+            for (auto& x : th) x.join();
+        }
+    }
+
+private:
+    static constexpr size_t MIN_BYTES = (size_t)16 << 20, CHUNK = (size_t)32 << 20;
+    static constexpr unsigned THREADS = 8;
+    struct Stage {
+        uint8_t* pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2];
+        bool ready = false;
+        void ensure()
+        {
+            if (ready) return;
+            for (int k = 0; k < 2; k++) {
+                EDSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin[k]), CHUNK, hipHostMallocPortable));
+                EDSX_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+            }
+            ready = true;
+        }
+    };
+};
 
 // ---- wave64 primitives -------------------------------------------------------------------
 __device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

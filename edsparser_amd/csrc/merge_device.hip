@@ -864,10 +864,10 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     hipLaunchKernelGGL(k_fin_write, dim3(2048), dim3(256), 0, st, fp, nstr);
     // malloc'ed, not value-initialised (see HostBytes): the pages are first touched by the copy
     out.take(E + 1);
-    EDSX_HIP(hipMemcpyAsync(out.data, d_out_.ptr, E, hipMemcpyDeviceToHost, st));
+    PinnedDownload::copy(out.data, d_out_.ptr, E, st);
     if (linear) {
         seds_out.take(Q + 1);
-        EDSX_HIP(hipMemcpyAsync(seds_out.data, d_sout_.ptr, Q, hipMemcpyDeviceToHost, st));
+        PinnedDownload::copy(seds_out.data, d_sout_.ptr, Q, st);
     } else seds_out.take(0);
     EDSX_HIP(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));

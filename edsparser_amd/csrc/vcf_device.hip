@@ -1153,8 +1153,8 @@ void VcfPipeline::run(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, si
     // std::string::resize costs as much as the whole device part for a 134 MB output)
     eds.take(Etot);
     seds.take(Qtot);
-    if (Etot) EDSX_HIP(hipMemcpyAsync(eds.data, d_eds_.ptr, Etot, hipMemcpyDeviceToHost, st));
-    if (Qtot) EDSX_HIP(hipMemcpyAsync(seds.data, d_seds_.ptr, Qtot, hipMemcpyDeviceToHost, st));
+    PinnedDownload::copy(eds.data, d_eds_.ptr, Etot, st);
+    PinnedDownload::copy(seds.data, d_seds_.ptr, Qtot, st);
     EDSX_HIP(hipStreamSynchronize(st));
     EDSX_HIP(hipGetLastError());
     stats.variant_groups = ngrp;                             // :724-726

@@ -268,3 +268,18 @@ def test_device_tokeniser_hands_odd_text_to_the_host(ctx):
         got.pop("code", None)
         assert got == want, (eds, seds)
         assert ctx.leds_tokenised_on_device(), (eds, seds)
+
+
+def test_large_downloads_every_size_remainder(ctx):
+    """Outputs of 16 MB and more come back through pinned chunks copied by eight host threads (PinnedDownload): the
+    split must cover sizes with every remainder modulo the thread count and the 64-byte rounding (a first version
+    dropped the last len % 8 bytes when len / 8 was a multiple of 64 — found by the full-size configs[2] run)."""
+    import hashlib
+    base = b"{A,C}" + b"G" * 59                      # 64 bytes per unit, merges to itself for l <= 59
+    unit_n = (17 << 20) // 64
+    for extra in range(0, 18):
+        eds = base * unit_n + b"{A,C}" + b"T" * extra
+        out, so = ctx.leds_merge(eds, None, 8, True)
+        want = (base.replace(b"{A,C}", b"{A,C}") * unit_n + b"{A,C}" + b"T" * extra + b"\n")
+        assert len(out) == len(want) and hashlib.sha256(out).digest() == hashlib.sha256(want).digest(), extra
+        assert so == b""
