@@ -227,3 +227,28 @@ def test_randomized_campaign(ctx):
             except edsparser_amd.EdsxError as ex:
                 got = ("ERR", ex.message)
             assert got == want, (it, l, desc)
+
+
+@pytest.mark.parametrize("L", [1_200_003, 1_200_064, 1_200_777])
+def test_host_buffer_path_large_outputs_equal_device_path(ctx, L):
+    """edsx_msa_transform (host bytes in, host bytes out) with a .seds of ≈40 MB: the text comes back through the
+    pinned-chunk download into a huge-page-advised buffer and must be the bytes the device-resident path holds in HBM
+    (torch's own copy), for output sizes with different remainders."""
+    import hashlib
+    import torch
+    import edsparser_amd
+    S = 200
+    n = edsparser_amd.synth_size(S, L)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_synth_device(buf.data_ptr(), n, S, L, seed=L)
+    E, Q = ctx.msa_plan_device(buf.data_ptr(), n, 0)
+    d_eds = torch.empty(E + 16, dtype=torch.uint8, device="cuda:0")
+    d_seds = torch.empty(Q + 16, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_emit_device(d_eds.data_ptr(), d_seds.data_ptr())
+    torch.cuda.synchronize()
+    assert Q >= 16 << 20
+    want_e, want_s = d_eds[:E].cpu().numpy().tobytes(), d_seds[:Q].cpu().numpy().tobytes()
+    eds, seds = ctx.msa_transform(bytes(buf.cpu().numpy()), 0)
+    assert (len(eds), len(seds)) == (E, Q)
+    assert hashlib.sha256(eds).digest() == hashlib.sha256(want_e).digest()
+    assert hashlib.sha256(seds).digest() == hashlib.sha256(want_s).digest()
