@@ -252,3 +252,22 @@ def test_device_tokeniser_is_taken_and_equals_the_host_tokeniser(ctx):
         finally:
             del os.environ["EDSX_HOST_TOKENIZER"]
         assert got == host == _want(vcf, fasta), it
+
+
+def test_large_outputs_every_size_remainder(ctx):
+    """.eds of 17 MB and more (pinned-chunk download): reference lengths with every remainder modulo the copy threads
+    and the 64-byte rounding, a handful of records, against the oracle."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    base = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 17_825_800, dtype=np.uint8)].tobytes()
+    hdr = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0\tS1\n"
+    for extra in range(0, 12):
+        ref = base[:17_825_792 - 40 + extra]          # .eds = reference + a few braces: sizes step through all remainders
+        fasta = b">c\n" + ref + b"\n"
+        recs = [(1000, "0|1\t1|1"), (9_000_000, "1|0\t0|0"), (len(ref) - 5, "0|0\t0|1")]
+        vcf = (hdr + "".join("c\t%d\t.\t%s\t%s\t.\t.\t.\tGT\t%s\n" % (p, chr(ref[p - 1]), "A" if chr(ref[p - 1]) != "A" else "C", g)
+                             for p, g in recs)).encode()
+        want = o.vcf(vcf, fasta, 0)
+        got = ctx.vcf_transform(vcf, fasta, 0)
+        assert len(got[0]) >= 16 << 20
+        assert got == want, extra
