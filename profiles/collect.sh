@@ -3,10 +3,10 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_v4 -o v4 --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-baseline-mb 0 > $R/gpurun_out/prof_v4.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_v5 -o v5 --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-baseline-mb 0 > $R/gpurun_out/prof_v5.log 2>&1
 echo "stats rc=$?"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_v4_fetch -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline-mb 0 > $R/gpurun_out/pmc_v4_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_v5_fetch -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline-mb 0 > $R/gpurun_out/pmc_v5_fetch.log 2>&1
 echo "fetch rc=$?"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_v4_write -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline-mb 0 > $R/gpurun_out/pmc_v4_write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_v5_write -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline-mb 0 > $R/gpurun_out/pmc_v5_write.log 2>&1
 echo "write rc=$?"
-tail -1 $R/gpurun_out/prof_v4.log | cut -c1-300
+tail -1 $R/gpurun_out/prof_v5.log | cut -c1-300
