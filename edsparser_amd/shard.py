@@ -115,6 +115,8 @@ def main(argv=None):
     a = parse(sys.argv[1:] if argv is None else argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("EDSX_SHARE_GPU"):                       # rehearsal on a one-GPU box: every rank uses cuda:0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("EDSX_DIST_BACKEND", "nccl")      # nccl = RCCL
     if backend == "nccl":

@@ -1,0 +1,52 @@
+"""GPU test of the multi-GPU front end as a user starts it: torch.distributed.run with two ranks (they share the box's
+one GPU: EDSX_SHARE_GPU=1, gloo for the object collectives), files in, files out, compared with the oracle."""
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+import oracle_lib as o
+from test_merge_shard_cpu import shaped_eds
+from test_vcf_shard_cpu import _free_port, _random_records, _vcf
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(args):
+    env = dict(os.environ, EDSX_SHARE_GPU="1", EDSX_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "edsparser_amd.shard"] + args
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+
+
+def test_vcf2eds_front_end(tmp_path):
+    rng = random.Random(77)
+    ref = "".join(rng.choice("ACGT") for _ in range(60000))
+    recs = _random_records(rng, ref, 5000, 8)
+    vcf, fasta = _vcf(ref, recs, 8)
+    (tmp_path / "x.vcf").write_bytes(vcf)
+    (tmp_path / "ref.fa").write_bytes(fasta)
+    r = _launch(["vcf2eds", "-i", str(tmp_path / "x.vcf"), "-r", str(tmp_path / "ref.fa")])
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = o.vcf(vcf, fasta, 0)
+    assert (tmp_path / "x.eds").read_bytes() == want[0] and (tmp_path / "x.seds").read_bytes() == want[1]
+    assert "Variant groups created:     %d" % want[2]["variant_groups"] in r.stdout
+
+
+def test_eds2leds_front_end_and_error_exit(tmp_path):
+    rng = random.Random(78)
+    eds, seds = shaped_eds(rng, 2000, 12, True, True)
+    (tmp_path / "g.eds").write_bytes(eds)
+    (tmp_path / "g.seds").write_bytes(seds)
+    r = _launch(["eds2leds", "-i", str(tmp_path / "g.eds"), "-s", str(tmp_path / "g.seds"), "-l", "12"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = o.merge(eds, seds, 12, True)
+    assert (tmp_path / "g_l12.leds").read_bytes() == want[0] and (tmp_path / "g_l12.seds").read_bytes() == want[1]
+    assert "Symbol ranges: 2" in r.stdout
+    (tmp_path / "bad.eds").write_bytes(b"{A,C}{G")
+    r = _launch(["eds2leds", "-i", str(tmp_path / "bad.eds"), "-l", "3"])
+    assert r.returncode != 0 and "Error: Expected '}'" in r.stderr
