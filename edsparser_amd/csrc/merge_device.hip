@@ -19,6 +19,7 @@
 //   symbols           size[i], ent_off[i], len1[i] (length of the only string when size == 1)
 //                     for the current round, double buffered.
 #include "merge_device.hpp"
+#include <chrono>
 #include <thread>
 
 #include <algorithm>
@@ -630,6 +631,15 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
 {
     if (l == 0) throw ParamError("context_length must be > 0 for l-EDS transformation");   // :322-324
     const bool linear = seds != nullptr;
+    // EDSX_TRACE=1: wall-clock of the host-visible stages on stderr (every mark follows a stream synchronisation)
+    static const bool trace = [] { const char* e = getenv("EDSX_TRACE"); return e && atoi(e); }();
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[edsx merge] %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
 
     // ---- tokenise: on the device when the text is plain (see "device tokenisers"), else on the host
     ctl_.ensure(8 * 16);
@@ -638,6 +648,7 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     bool head_single = false, tail_single = false;
     const bool on_device = tokenize_device(eds, eds_n, seds, seds_n, linear, st, n0, m, W, head_single, tail_single, head_len);
     tokenised_on_device_ = on_device;
+    mark(on_device ? "upload + device tokenise" : "device tokenise attempt");
     if (!on_device) {
     // ---- host tokeniser: eds.cpp:39-155 (same error texts)
     std::vector<uint8_t> chars;
@@ -769,6 +780,7 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
         EDSX_HIP(hipStreamSynchronize(st));
     }
     }
+    if (!on_device) mark("host tokenise + upload");
     if (shard) {
         shard->head_intact = shard->tail_intact = true;
         if ((shard->head_sentinel && !head_single) || (shard->tail_sentinel && !tail_single) ||
@@ -821,6 +833,7 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
         iteration++;
     }
     if (iteration >= MAX_ITERATIONS) throw FormatError("Maximum iterations reached without convergence");
+    mark("merge rounds");
 
     // ---- symbol range of a partitioned merge: did the sentinels stay out of every merge?  Merged symbols get
     // fresh pool entries (>= m), an untouched sentinel still points at its leaf.
@@ -862,6 +875,7 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     if (linear) d_sout_.ensure(Q + 16);
     fp.out = d_out_.as<uint8_t>(); fp.sout = d_sout_.as<uint8_t>();
     hipLaunchKernelGGL(k_fin_write, dim3(2048), dim3(256), 0, st, fp, nstr);
+    mark("final sizes");
     // malloc'ed, not value-initialised (see HostBytes): the pages are first touched by the copy
     out.take(E + 1);
     PinnedDownload::copy(out.data, d_out_.ptr, E, st);
@@ -873,6 +887,7 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     EDSX_HIP(hipStreamSynchronize(st));
     EDSX_HIP(hipGetLastError());
     if (hctl[4]) throw FormatError("l-EDS merge nesting deeper than this build supports");
+    mark("text kernel + download");
     out.data[E] = '\n';                                      // eds.cpp:630
     if (linear) seds_out.data[Q] = '\n';                     // eds.cpp:658
     if (shard && shard->tail_sentinel) {                     // not the last range: the text goes on
