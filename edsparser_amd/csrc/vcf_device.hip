@@ -20,6 +20,8 @@
 //                   bit matrix.
 #include "vcf_device.hpp"
 
+#include <hipcub/hipcub.hpp>     // DeviceRadixSort for unsorted VCFs with distinct positions (a commodity sort)
+
 #include <algorithm>
 #include <cstring>
 #include <sstream>
@@ -528,6 +530,10 @@ __global__ void k_vt_ascending(const u64* __restrict__ pos, u64 nrec, VtCtl* ctl
     for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j + 1 < nrec; j += (u64)gridDim.x * blockDim.x) un |= pos[j] >= pos[j + 1];
     if (un) ctl->t_alt = 1;                                      // scratch until the offset scans overwrite it
 }
+__global__ void k_vt_iota(u32* __restrict__ v, u64 n)
+{
+    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < n; j += (u64)gridDim.x * blockDim.x) v[j] = (u32)j;
+}
 // counts in sorted order (inputs of the four offset scans)
 __global__ void k_vt_gather(VtRec r, const u32* __restrict__ order, u64 nrec, u64* __restrict__ a, u64* __restrict__ b,
                             u64* __restrict__ c, u64* __restrict__ d)
@@ -812,7 +818,27 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
     // positions already ascend strictly (the usual VCF) or the caller hands the records over in final order.
     const u32* d_order = nullptr;
     std::vector<u32> order;
-    if (!presorted && h.t_alt) {
+    bool need_host_sort = !presorted && h.t_alt;
+    if (need_host_sort) {
+        // Not ascending.  If the positions are pairwise distinct there is exactly one sorted order, so a device radix
+        // sort gives the reference's permutation; equal positions (checked on the sorted keys) need the host's
+        // std::sort, whose unstable permutation of them is part of the output.
+        vt_s2_.ensure(8 * (nr + 2)); vt_s3_.ensure(4 * (nr + 2)); vt_order_.ensure(4 * (nr + 1));
+        hipLaunchKernelGGL(k_vt_iota, dim3(1024), dim3(256), 0, st, vt_s3_.as<u32>(), nr);
+        size_t tmp_bytes = 0;
+        EDSX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, vt_pos_.as<u64>(), vt_s2_.as<u64>(), vt_s3_.as<u32>(),
+                                                    vt_order_.as<u32>(), (int)nr, 0, 64, st));
+        vt_sorttmp_.ensure(tmp_bytes + 16);
+        EDSX_HIP(hipcub::DeviceRadixSort::SortPairs(vt_sorttmp_.ptr, tmp_bytes, vt_pos_.as<u64>(), vt_s2_.as<u64>(), vt_s3_.as<u32>(),
+                                                    vt_order_.as<u32>(), (int)nr, 0, 64, st));
+        VtCtl z{};
+        EDSX_HIP(hipMemcpyAsync(&ctl->t_alt, &z.t_alt, 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_vt_ascending, dim3(1024), dim3(256), 0, st, vt_s2_.as<u64>(), nr, ctl);   // sorted keys: strict?
+        EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        if (!h.t_alt) { need_host_sort = false; d_order = vt_order_.as<u32>(); }
+    }
+    if (need_host_sort) {
         std::vector<u64> hpos(nr);
         EDSX_HIP(hipMemcpy(hpos.data(), vt_pos_.ptr, 8 * nr, hipMemcpyDeviceToHost));
         order.resize(nr);
