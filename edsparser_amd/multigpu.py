@@ -314,7 +314,10 @@ class VcfSharder:
         if len(gpos) < 2 or bool(np.all(gpos[1:] > gpos[:-1])):
             order = np.arange(len(gpos), dtype=np.int64)           # strictly ascending: the sort cannot move anything
         else:
-            order = self.sort_fn(gpos).astype(np.int64)
+            order = np.argsort(gpos, kind="stable").astype(np.int64)
+            sp = gpos[order]
+            if bool(np.any(sp[1:] == sp[:-1])):                    # equal positions: the reference's std::sort decides
+                order = self.sort_fn(gpos).astype(np.int64)
         cuts, start, wraps = plan_vcf_cuts(gpos, greflen, order, world)
         # lines of mine that another rank's range needs, and the runs I keep
         outgoing = {}
