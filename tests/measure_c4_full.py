@@ -1,7 +1,7 @@
 """BASELINE configs[3] at full size on one GPU: 1 Gb reference (60-column FASTA) + 10^7-record synthetic VCF (sorted,
 distinct POS, 70 % SNP / 15 % insertion 1-10 / 15 % deletion 1-10, 8 diploid phased samples — SURVEY §8(d)).
 Times the single C ABI call, checks it against the CPU oracle (one core, timed as the CPU side) and against the 8-way
-position-range partition (ranks as threads on the one GPU).  Usage: python tests/measure_c4_full.py [scale]  (1.0 = full)"""
+position-range partition (ranks as threads on the one GPU).  Usage: python tests/measure_c4_full.py [scale] [shuffle]  (1.0 = full)"""
 import os
 import sys
 import time
@@ -47,6 +47,12 @@ def main():
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     t0 = time.perf_counter()
     vcf, fasta = gen(int(1_000_000_000 * scale), int(10_000_000 * scale), 8, 7)
+    if len(sys.argv) > 2 and sys.argv[2] == "shuffle":            # record lines in random order (distinct POS: device radix sort)
+        import random
+        lines = vcf.split(b"\n")
+        head, body = lines[:2], [x for x in lines[2:] if x]
+        random.Random(5).shuffle(body)
+        vcf = b"\n".join(head + body) + b"\n"
     print("generated VCF %.1f MB + FASTA %.1f MB in %.0f s" % (len(vcf) / 1e6, len(fasta) / 1e6, time.perf_counter() - t0), flush=True)
     os.environ["EDSX_TRACE"] = "1"
     ctx = edsparser_amd.Context(0)
