@@ -275,18 +275,25 @@ def plan_vcf_cuts(pos, reflen, order, world):
     return cuts, start, wraps
 
 
-def _line_runs(gidx, k0, base, off, length, vcf, lo):
-    """Records gidx (global file indices owned by this rank, in sorted order, first one at sorted index k0)
-    -> [(sorted index of the first record, text)], maximal runs of lines adjacent in the file as one slice."""
+def _line_runs(g_sel, k, base, off, length, vcf, lo):
+    """Records g_sel (global file indices owned by this rank, ascending sorted index k) as maximal runs of lines that
+    are adjacent both in the sorted order and in the file: -> (run_k int64[R], run_nbytes int64[R], blob) with the runs'
+    text back to back in `blob` (inner newlines kept, none between runs).  Arrays, not per-line tuples: a shuffled
+    file has as many runs as lines."""
     import numpy as np
-    if len(gidx) == 0:
-        return []
-    loc = (gidx - base).astype(np.int64)
+    if len(g_sel) == 0:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), b""
+    loc = (g_sel - base).astype(np.int64)
     o, ln = off[loc].astype(np.int64), length[loc].astype(np.int64)
-    brk = np.flatnonzero((np.diff(loc) != 1) | (o[:-1] + ln[:-1] + 1 != o[1:])) + 1
-    firsts = np.concatenate(([0], brk))
-    lasts = np.concatenate((brk, [len(loc)])) - 1
-    return [(k0 + int(a), bytes(vcf[lo + int(o[a]):lo + int(o[b] + ln[b])])) for a, b in zip(firsts, lasts)]
+    brk = np.flatnonzero((np.diff(k) != 1) | (np.diff(loc) != 1) | (o[:-1] + ln[:-1] + 1 != o[1:])) + 1
+    firsts = np.concatenate(([0], brk)).astype(np.int64)
+    lasts = np.concatenate((brk, [len(loc)])).astype(np.int64) - 1
+    b0, b1 = lo + o[firsts], lo + o[lasts] + ln[lasts]
+    if len(firsts) == 1:
+        blob = bytes(vcf[int(b0[0]):int(b1[0])])
+    else:
+        blob = b"".join([vcf[x:y] for x, y in zip(b0.tolist(), b1.tolist())])
+    return k[firsts].astype(np.int64), (b1 - b0).astype(np.int64), blob
 
 
 class VcfSharder:
@@ -321,28 +328,34 @@ class VcfSharder:
         cuts, start, wraps = plan_vcf_cuts(gpos, greflen, order, world)
         # lines of mine that another rank's range needs, and the runs I keep
         outgoing = {}
-        pieces = []
+        mine = None
         for d in range(world):
             g = order[cuts[d]:cuts[d + 1]]
             sel = np.flatnonzero((g >= base[rank]) & (g < base[rank + 1]))
             if len(sel) == 0:
                 continue
-            # runs must also be runs of the *sorted* order: split where the sorted index jumps
-            jumps = np.flatnonzero(np.diff(sel) != 1) + 1
-            runs = []
-            for a, b in zip(np.concatenate(([0], jumps)), np.concatenate((jumps, [len(sel)]))):
-                runs += _line_runs(g[sel[a:b]], cuts[d] + int(sel[a]), base[rank], off, length, vcf, lo)
+            runs = _line_runs(g[sel], cuts[d] + sel.astype(np.int64), base[rank], off, length, vcf, lo)
             if d == rank:
-                pieces += runs
+                mine = runs
             else:
                 outgoing[d] = runs
         everything = [None] * world
         self.dist.all_gather_object(everything, outgoing)
-        for r in range(world):
-            if r != rank and rank in everything[r]:
-                pieces += everything[r][rank]
-        pieces.sort(key=lambda p: p[0])
-        lines = b"\n".join(p[1] for p in pieces)
+        sources = ([mine] if mine is not None else []) + [everything[r][rank] for r in range(world)
+                                                         if r != rank and rank in everything[r]]
+        if not sources:
+            lines = b""
+        elif len(sources) == 1 and len(sources[0][0]) == 1:
+            lines = sources[0][2]
+        else:
+            run_k = np.concatenate([x[0] for x in sources])
+            run_n = np.concatenate([x[1] for x in sources])
+            blob_base = np.concatenate(([0], np.cumsum([len(x[2]) for x in sources])))[:-1]
+            run_off = np.concatenate([bb + np.concatenate(([0], np.cumsum(x[1])))[:-1] for bb, x in zip(blob_base, sources)])
+            text = b"".join(x[2] for x in sources)
+            by_k = np.argsort(run_k, kind="stable")
+            s0, s1 = run_off[by_k], (run_off + run_n)[by_k]
+            lines = b"\n".join([text[x:y] for x, y in zip(s0.tolist(), s1.tolist())])
         nonempty = [r for r in range(world) if cuts[r] < cuts[r + 1]]
         n_mine = cuts[rank + 1] - cuts[rank]
         eds = seds = b""
@@ -371,7 +384,7 @@ class VcfSharder:
         stats["variant_groups"] = sum(s[2] for s in sizes)
         self.last = {
             "eds": eds, "seds": seds, "stats": stats, "cuts": cuts, "records": n_mine, "wraps": wraps,
-            "moved_lines_bytes": sum(len(t) for runs in outgoing.values() for _, t in runs),
+            "moved_lines_bytes": sum(len(x[2]) for x in outgoing.values()),
             "eds_offset": sum(s[0] for s in sizes[:rank]), "seds_offset": sum(s[1] for s in sizes[:rank]),
             "eds_total": sum(s[0] for s in sizes), "seds_total": sum(s[1] for s in sizes),
         }
