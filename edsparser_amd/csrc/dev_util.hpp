@@ -87,6 +87,15 @@ private:
     };
 };
 
+// The device tokenisers keep a few u64 per input byte (flags and their scans): fine for the GB-sized texts they are
+// meant for, but a text whose scratch would not fit comfortably is left to the host tokenisers instead of failing.
+inline bool device_scratch_fits(size_t bytes)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    return bytes <= free_b / 2;
+}
+
 // ---- wave64 primitives -------------------------------------------------------------------
 __device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // number of set bits of `mask` strictly below this lane

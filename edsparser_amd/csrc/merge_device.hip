@@ -560,6 +560,7 @@ bool MergePipeline::tokenize_device(const uint8_t* eds, size_t eds_n, const uint
     while (send && std::isspace(seds[send - 1])) send--;
     if (end == 0 || end >= 0xfffffff0ull || (linear && (send == 0 || send >= 0xfffffff0ull))) return false;
     const size_t nmax = std::max(end, send);
+    if (!device_scratch_fits(41 * nmax)) return false;          // raw text + five u64 arrays per byte
     d_raw_.ensure(nmax + 16);
     for (DevBuf* b : {&tk_a_, &tk_b_, &tk_c_, &tk_d_, &tk_e_}) b->ensure(8 * (nmax + 2));
     scan_tmp_.ensure(8 * ((nmax + 2) / SCAN_TILE + 4));

@@ -786,7 +786,7 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
 {
     { const char* e = getenv("EDSX_HOST_TOKENIZER"); if (e && atoi(e)) return false; }      // A/B switch for the parity tests
     nrec = 0; max_samples = 0;
-    if (n == 0) return false;
+    if (n == 0 || !device_scratch_fits(17 * n)) return false;   // raw text + two u64 arrays per byte
     vt_raw_.ensure(n + 16);
     vt_flag_.ensure(8 * (n + 2)); vt_idx_.ensure(8 * (n + 2));
     scan_tmp_.ensure(8 * ((n + 2) / SCAN_TILE + 4));
@@ -880,7 +880,7 @@ bool VcfPipeline::index_device(const uint8_t* vcf, size_t n, hipStream_t st, std
                                std::vector<u64>& line_off, std::vector<u64>& line_len, VcfCounters& stats)
 {
     { const char* e = getenv("EDSX_HOST_TOKENIZER"); if (e && atoi(e)) return false; }
-    if (n == 0) return false;
+    if (n == 0 || !device_scratch_fits(17 * n)) return false;
     vt_raw_.ensure(n + 16);
     vt_flag_.ensure(8 * (n + 2)); vt_idx_.ensure(8 * (n + 2));
     scan_tmp_.ensure(8 * ((n + 2) / SCAN_TILE + 4));
