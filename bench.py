@@ -38,6 +38,10 @@ def parse_args():
                     help="size of the CPU-baseline sample in MB (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0")
+    ap.add_argument("--verify", type=int, default=1,
+                    help="N=1, context length 0: after the timed region compare sampled column windows of the outputs "
+                         "(spread over the whole width, incl. offsets beyond 4 GiB and the last columns) with the CPU "
+                         "oracle (tests/fullsize_verify.py); 0 = skip")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     return ap.parse_args()
@@ -170,6 +174,12 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": alg, "algorithmic_bytes": what}
+        verify = None
+        if world == 1 and a.verify and l == 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from fullsize_verify import verify_windows
+            verify = verify_windows(ctx, torch, S, L, a.seed, a.variant_fraction, out["eds"], out["seds"],
+                                    out["E"], out["Q"])
         cpu = None
         if world == 1 and a.cpu_baseline_mb > 0:
             cpu = cpu_baseline(ctx, torch, S, a.cpu_baseline_mb, a.variant_fraction, a.seed, l)
@@ -187,7 +197,7 @@ def main():
                        "slow_segments": info["n_slow_segments"],
                        "partition": "columns x %d" % world},
             "frac_of_hbm_read_roofline": round(value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4),
-            "roofline": roof, "cpu_baseline": cpu, "kernel_ms": per_kernel,
+            "roofline": roof, "cpu_baseline": cpu, "verify": verify, "kernel_ms": per_kernel,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

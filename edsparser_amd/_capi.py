@@ -85,6 +85,7 @@ def load_library():
     lib.edsx_msa_last_info.argtypes = [ctypes.c_void_p, P(MsaInfo)]
     lib.edsx_msa_edge_info.argtypes = [ctypes.c_void_p, P(MsaEdges)]
     lib.edsx_msa_copy_columns.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    lib.edsx_msa_locate_segment.argtypes = [ctypes.c_void_p, ctypes.c_uint64] + [P(ctypes.c_uint64)] * 4
     lib.edsx_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.edsx_get_timing.argtypes = [ctypes.c_void_p, P(ctypes.c_char_p), P(ctypes.c_float), P(ctypes.c_int),
                                     ctypes.c_int]
@@ -230,6 +231,12 @@ class Context:
         buf = ctypes.create_string_buffer(n_rows * ncols)
         self._check(self._lib.edsx_msa_copy_columns(self._h, col0, ncols, buf))
         return buf.raw
+
+    def msa_locate_segment(self, col):
+        """-> (segment index, start column, .eds offset, .seds offset) of the first segment starting at or after col"""
+        v = [ctypes.c_uint64() for _ in range(4)]
+        self._check(self._lib.edsx_msa_locate_segment(self._h, int(col), *[ctypes.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
 
     def set_timing(self, on):
         self._lib.edsx_set_timing(self._h, 1 if on else 0)

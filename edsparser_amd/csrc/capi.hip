@@ -133,6 +133,16 @@ int edsx_msa_copy_columns(edsx_ctx* ctx, uint64_t col0, uint64_t ncols, uint8_t*
     });
 }
 
+int edsx_msa_locate_segment(edsx_ctx* ctx, uint64_t col, uint64_t* seg, uint64_t* seg_col, uint64_t* eds_off,
+                            uint64_t* seds_off)
+{
+    return guarded(ctx, [&] {
+        if (!seg || !seg_col || !eds_off || !seds_off) throw ParamError("null argument");
+        const MsaPipeline::SegLoc r = ctx->msa.locate(col, nullptr);
+        *seg = r.seg; *seg_col = r.col; *eds_off = r.eds_off; *seds_off = r.seds_off;
+    });
+}
+
 void edsx_set_timing(edsx_ctx* ctx, int enabled) { if (ctx) ctx->msa.set_timing(enabled != 0); }
 int edsx_get_timing(edsx_ctx* ctx, const char** names, float* total_ms, int* launches, int cap)
 {

@@ -1071,6 +1071,12 @@ __device__ __forceinline__ uint4 bytes_eq_mask(const uint4& a, uint32_t cccc)
                       ~bytes_ne_mask(a.w, cccc));
 }
 __device__ __forceinline__ bool any4(const uint4& v) { return (v.x | v.y | v.z | v.w) != 0; }
+// does this lane hold a NUL byte in one of its existing rows?
+__device__ __forceinline__ bool any_nul(const uint4& c, const uint4& vmask)
+{
+    const uint4 z = bytes_eq_mask(c, 0u);
+    return ((z.x & vmask.x) | (z.y & vmask.y) | (z.z & vmask.z) | (z.w & vmask.w)) != 0;
+}
 __device__ __forceinline__ u32 first_byte_index(const uint4& m)   // m bytes are 0x00 / 0xFF
 {
     return m.x ? (u32)__builtin_ctz(m.x) >> 3
@@ -1269,10 +1275,13 @@ __device__ __forceinline__ bool fast_group_dna1(const uint4& x, const uint4& vma
 // Group the rows of a fast segment (msa_transforms.cpp:262-293: distinct gap-stripped strings in
 // order of first appearance).  Returns false when the segment must take the generic path.
 //   one column : exact, SWAR byte compares.
-//   2..64 cols : every row's gap-stripped string is hashed once (3 multiplicative chains with 24-bit
-//                state, v_mad_u32_u24 = full rate, fed only by its non-gap letters, + its length),
-//                rows are grouped by that signature.  The cost does not depend on the number of
-//                groups; two different strings of one segment collide with probability ~2^-72.
+//   2..10 cols over {A,C,G,T,N,-}: exact 3-bit-per-column keys.
+//   otherwise  : every row gets a 96-bit additive signature of its raw column bytes (gaps normalised
+//                to 0; v_mad_u32_u24 = full rate); rows with equal signatures are PROPOSED as a raw
+//                group and then compared with the group's first row byte for byte (phase B), so the
+//                grouping is exact; raw groups that spell the same string are joined by their
+//                stripped string (verbatim key up to 12 letters; longer strings that hash alike send
+//                the segment to the generic kernels).  NUL bytes (msa_transforms.cpp:282) -> generic.
 // NR: rows per lane that can exist (16; 4 when S <= 256)
 template <bool CHECK_NL, int NR>
 __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 meta, const uint4& col0, u32 lane,
@@ -1287,6 +1296,8 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
         if (fast_group_dna1(col0, vmask, lane, G)) return true;
         G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
         G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
+        // a NUL byte ends the row's string in the reference (msa_transforms.cpp:282): exact kernels only
+        if (ballot64(any_nul(col0, vmask))) return false;
         const uint4 col = normalise_col<CHECK_NL>(col0, vmask, saw_nl);
         while (ballot64(any4(rm))) {
             int leader;
@@ -1376,8 +1387,9 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
 
     // ---- phase A: raw signatures of the 16 rows of this lane: sig_j(row) = sum_c byte(row,c) * W_j(c)
     // (gaps are 0 and contribute nothing; v_mad_u32_u24 is full rate).  Rows with equal normalised
-    // columns get equal signatures; different rows collide with probability ~2^-96.
+    // columns get equal signatures; a collision of different rows is caught by the comparison in phase B.
     u32 h1[16], h2[16], h3[16];
+    u32 nul = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) { h1[i] = 0; h2[i] = 0; h3[i] = 0; }
     auto weight = [](u32 c, u32 j) -> u32 { return FAST_W.v[c * 3u + j]; };
@@ -1396,6 +1408,7 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (c0 + j < ncol) {
+                nul |= any_nul(cvs[j], vmask) ? 1u : 0u;
                 const uint4 cn = normalise_col<CHECK_NL>(cvs[j], vmask, saw_nl);
                 const u32 w1 = weight(c0 + j, 0), w2 = weight(c0 + j, 1), w3 = weight(c0 + j, 2);
                 EDSX_H(0) EDSX_H(1) EDSX_H(2) EDSX_H(3) EDSX_H(4) EDSX_H(5) EDSX_H(6) EDSX_H(7)
@@ -1404,6 +1417,13 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
         }
     }
 #undef EDSX_H
+    if (ballot64(nul != 0)) return false;              // msa_transforms.cpp:282: left to the exact generic kernels
+#ifdef EDSX_TEST_WEAK_SIG
+    // test-only build: one bit of signature, so that different rows collide all the time and the
+    // byte-for-byte verification in phase B is what keeps the groups right
+#pragma unroll
+    for (int i = 0; i < 16; i++) { h1[i] &= 1u; h2[i] = 0; h3[i] = 0; }
+#endif
     // ---- phase B: raw groups in order of first appearance; each is keyed by a 96-bit hash of its
     // representative's gap-stripped string (+ length), so that raw groups spelling the same string
     // (same letters, other gap placement) fall together in fast_assign
@@ -1426,6 +1446,19 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
             if (h1[i + 12] == r1 && h2[i + 12] == r2 && h3[i + 12] == r3) e3 |= 0xffu << (i * 8);
         }
         const uint4 eq = make_uint4(e0 & rm.x, e1 & rm.y, e2 & rm.z, e3 & rm.w);
+        // The signature only proposes the group: every member is now compared with the leader byte for
+        // byte over all columns (gaps normalised as above).  A mismatch is a signature collision: the
+        // segment goes to the generic kernels, which compare rows exactly.
+        {
+            u32 mism = 0;
+            for (u32 c = 0; c < ncol; c++) {               // (one load at a time: this path is rare, registers are not)
+                u32 dummy = 0;
+                const uint4 cn = normalise_col<false>(c == 0 ? col0 : load16u(col_ptr(c)), vmask, dummy);
+                const u32 lb = leader_byte(cn, leader, i0) * 0x01010101u;
+                mism |= ((cn.x ^ lb) & eq.x) | ((cn.y ^ lb) & eq.y) | ((cn.z ^ lb) & eq.z) | ((cn.w ^ lb) & eq.w);
+            }
+            if (ballot64(mism != 0)) return false;
+        }
         // the representative's string: lane = column
         const u32 rep_row = i0 * 64u + (u32)leader;
         u32 ch = 0;
@@ -1454,7 +1487,14 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
             }
         }
         t1 = wave_xor_all(t1); t2 = wave_xor_all(t2); t3 = wave_xor_all(t3);
+#ifdef EDSX_TEST_WEAK_SIG
+        if (len > 12u) { t1 &= 1u; t2 = 0; t3 = 0; }
+#endif
         const u64 klo = ((u64)t2 << 32) | t1, khi = ((u64)len << 32) | t3;
+        // Keys of up to 12 letters are the string itself.  Longer ones are hashed: an equal key then only
+        // SUGGESTS that two raw groups (same letters, other gap placement) spell one string, so such a
+        // segment is left to the exact generic kernels.
+        if (len > 12u && ballot64(lane < G.k && G.key_lo == klo && G.key_hi == khi)) return false;
         if (!fast_assign(G, rm, eq, klo, khi, len, lane, rep_row)) return false;
     }
     return true;
@@ -2312,6 +2352,31 @@ MsaPipeline::Edges MsaPipeline::edge_info(hipStream_t st)
     e.leds = h_.E - el[0];
     e.lseds = h_.Q - slo[0];
     return e;
+}
+
+// first segment that starts at or after alignment column `col` (binary search over the device table, one
+// 8-byte copy per probe: a reporting / verification helper, not on the transform path)
+MsaPipeline::SegLoc MsaPipeline::locate(u64 col, hipStream_t st)
+{
+    if (!planned_) throw ParamError("locate needs a planned alignment");
+    const u64 nseg = h_.nseg;
+    auto at = [&](const u64* arr, u64 i) -> u64 {
+        u64 v = 0;
+        EDSX_HIP(hipMemcpyAsync(&v, arr + i, 8, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        return v;
+    };
+    u64 lo = 0, hi = nseg;                                  // seg_start[nseg] == L
+    while (lo < hi) {
+        const u64 mid = lo + (hi - lo) / 2;
+        if (at(seg_start_p_, mid) >= col) hi = mid; else lo = mid + 1;
+    }
+    SegLoc r{};
+    r.seg = lo;
+    r.col = lo < nseg ? at(seg_start_p_, lo) : h_.L;
+    r.eds_off = lo < nseg ? at(eds_len_.as<u64>(), lo) : h_.E;
+    r.seds_off = lo < nseg ? at(seds_len_.as<u64>(), lo) : h_.Q;
+    return r;
 }
 
 void MsaPipeline::copy_columns(u64 col0, u64 ncols, uint8_t* host_out, hipStream_t st)

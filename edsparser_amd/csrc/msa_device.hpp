@@ -144,6 +144,8 @@ public:
     struct Edges { u64 nseg, fvar, fcols, feds, fseds, lvar, lcols, leds, lseds; };
     Edges edge_info(hipStream_t st);
     void copy_columns(u64 col0, u64 ncols, uint8_t* host_out, hipStream_t st);
+    struct SegLoc { u64 seg, col, eds_off, seds_off; };
+    SegLoc locate(u64 col, hipStream_t st);
     bool planned() const { return planned_; }
     size_t msa_bytes() const { return n_; }
 

@@ -153,6 +153,12 @@ int edsx_msa_edge_info(edsx_ctx* ctx, edsx_msa_edges* out);
 /* Alignment columns [col0, col0+ncols) of every row of the planned alignment, row-major
  * (n_rows * ncols bytes) into a host buffer. */
 int edsx_msa_copy_columns(edsx_ctx* ctx, uint64_t col0, uint64_t ncols, uint8_t* host_out);
+/* First segment of the planned alignment that starts at or after alignment column `col`: its index, start
+ * column and the byte offsets of its text in the .eds / .seds outputs (index n_segments, column n_cols and
+ * the output sizes when no segment starts there).  Lets a caller cut the device-resident outputs at segment
+ * boundaries, e.g. to check sampled column windows of a 100 GB alignment against the CPU path. */
+int edsx_msa_locate_segment(edsx_ctx* ctx, uint64_t col, uint64_t* seg, uint64_t* seg_col, uint64_t* eds_off,
+                            uint64_t* seds_off);
 
 /* Per-kernel device time, measured with HIP events on the stream each kernel is launched on and
  * accumulated over all plan/emit calls since edsx_set_timing(ctx, 1).  Arrays of capacity cap;

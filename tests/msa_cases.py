@@ -73,3 +73,57 @@ def campaign_msa(rng):
         out.extend(s[k:k + lw] for k in range(0, L, lw))
     trailing = rng.choice(["\n", "\n", "", "\n\n"])
     return ("\n".join(out) + trailing).encode(), (S, L, lw, alph, p_var, p_gap, p_row)
+
+
+def wide_msa(rng, S=None, nul=False, alph=None):
+    """Alignments whose variant segments are WIDE (2..70 adjacent variant columns) and whose rows are drawn
+    from a few haplotypes, some of them the same letters with the gaps placed differently (so that different
+    raw rows spell one string, also strings of more than 12 letters) — the multi-column signature path of the
+    wave-per-segment kernels and its byte-for-byte verification.  nul=True sprinkles NUL bytes into variant
+    columns (the reference ends a row's string at '\\0', msa_transforms.cpp:282) and makes some columns NUL
+    in every row."""
+    S = S or rng.choice([2, 3, 7, 40, 64, 65, 200, 256, 257, 700, 1000, 1024])
+    alph = alph or rng.choice(["ACGT", "ACGTN", "ACGTacgtN", "ACDEFGHIKLMNPQRSTVWY"])
+    nblocks = rng.randint(1, 6)
+    cols = []          # list of per-column lists (one char per row)
+    def common(n):
+        for _ in range(n):
+            ch = rng.choice(alph)
+            cols.append([ch] * S)
+    common(rng.randint(0, 5))
+    for _ in range(nblocks):
+        w = rng.choice([2, 5, 10, 11, 12, 13, 20, 21, 30, 63, 64, 65, 70, rng.randint(2, 70)])
+        nh = rng.randint(1, 6)
+        haps = []
+        for h in range(nh):
+            letters = [rng.choice(alph) for _ in range(rng.randint(0, w))]
+            for variant in range(rng.randint(1, 3)):     # same letters, gaps placed differently
+                pos = sorted(rng.sample(range(w), len(letters)))
+                row = ["-"] * w
+                for p, ch in zip(pos, letters):
+                    row[p] = ch
+                haps.append(row)
+        pick = [rng.randrange(len(haps)) for _ in range(S)]
+        # make sure the block is variant in every column w.r.t. row 0 or row 0 has a gap there: force it by
+        # giving one row the complement letter where needed
+        for c in range(w):
+            col = [haps[pick[r]][c] for r in range(S)]
+            if col[0] != "-" and all(x == col[0] for x in col):
+                r = rng.randrange(1, S) if S > 1 else 0
+                col[r] = "-" if rng.random() < 0.5 else rng.choice([a for a in alph if a != col[0]] or ["-"])
+            if nul and rng.random() < 0.15:
+                for _ in range(rng.randint(1, 3)):
+                    col[rng.randrange(S)] = "\0"
+            cols.append(col)
+        common(rng.randint(1, 40))
+        if nul and rng.random() < 0.3:
+            cols.append(["\0"] * S)                       # a NUL in every row: a common column
+            common(rng.randint(1, 3))
+    L = len(cols)
+    lw = rng.choice([L, L, 60, 7])
+    out = []
+    for r in range(S):
+        out.append(">w%d" % r)
+        s = "".join(cols[c][r] for c in range(L))
+        out.extend(s[k:k + lw] for k in range(0, L, lw))
+    return ("\n".join(out) + rng.choice(["\n", ""])).encode("latin-1")
