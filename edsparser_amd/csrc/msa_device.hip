@@ -14,16 +14,16 @@
 //                 rows (msa_transforms.cpp:268-269) and c for one-line rows.
 //   Vraw / V      1 bit per raw position / alignment column: 1 = variant column (some row differs
 //                 from row 0, or row 0 has '-').  Complement of the reference's bit-vector B.
-//   vc            the variant columns only, column-major: vc[slot * Spad + vc_pos(r)] = byte of row r
-//                 (rows permuted so that a lane's 16-byte load holds rows lane, lane+64, ...).
+//   vc            the variant columns only, column-major: vc[slot * Spad + r] = byte of row r
+//                 (natural row order: a lane's 16-byte load at 16*lane holds rows 16*lane .. +15).
 //                 Slots are handed out per tile by an atomic counter (unordered between tiles,
 //                 consecutive inside a 64-column word); word_slot[w] = slot of the first variant
 //                 column of raw word w.  Every later kernel reads rows through vc, so the S x L
 //                 matrix is read from HBM exactly once.
 //   run/seg table seg_start[nseg+1] (alignment columns), bitmap Hseg of segment starts with a
 //                 per-word prefix segbase[]; a segment is common iff V[seg_start] == 0.
-//   grec          one grouping record per variant segment (count -> emit): group id of every row (one
-//                 byte, lane-major like vc), representative row and letter of every group, k.
+//   rec           one grouping record per variant segment (count -> emit): group id of every row (2 or 4
+//                 bits, natural row order), number of strings, representative rows / the .eds text.
 //   eds_off/seds_off  exclusive scans of the per-segment text sizes.
 #include "msa_device.hpp"
 
@@ -276,7 +276,7 @@ __global__ void k_index_rows(const uint8_t* __restrict__ f, u64 n, MsaHdr* h,
 struct K1Params {
     const uint8_t* file; const u64* row_start; MsaHdr* hdr;
     u64* Vraw; u64* word_slot; uint8_t* vc; u64 vc_cap_cols;
-    u64 Draw, lw; u32 S, Spad, Gp, cpr_log2, cap_cols /* LDS colbuf capacity in columns */;
+    u64 Draw, lw; u32 S, Spad, cpr_log2, cap_cols /* LDS colbuf capacity in columns */;
     u64 ntiles;
 };
 
@@ -337,12 +337,10 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 
     const uint8_t* f = p.file;
     const u32 Sm1 = p.S - 1;
-    // rows of this thread.  Plain: sub, sub + RI, ...  Lane rows (S <= 1024, RI == 4 * Gp): the rows
-    // whose bytes are consecutive in a vc column, vc_pos(row_of(it)) == sub * 16 + it:
-    //   row_of(it) = sub * (16 / Gp) + it / Gp + 64 * (it % Gp)      (Gp = 16: sub + 64 * it)
-    const u32 gl = 31u - (u32)__builtin_clz(p.Gp);             // log2(Gp), Gp a power of two
+    // rows of this thread.  Plain: sub, sub + RI, ...  Lane rows (16 * RI >= S): 16 consecutive rows
+    // 16*sub .. 16*sub+15, i.e. 16 consecutive bytes of a vc column (natural row order).
     auto row_of = [&](u32 it) -> u32 {
-        if constexpr (LANEROWS) return (sub << (4u - gl)) + (it >> gl) + 64u * (it & (p.Gp - 1u));
+        if constexpr (LANEROWS) return sub * 16u + it;
         else return sub + it * RI;
     };
     uint4 ref = make_uint4(0, 0, 0, 0);
@@ -451,16 +449,17 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                     if (V16 & (1u << I)) {                                                     \
                         if (idx >= b0 && idx < b0 + cap) {                                     \
                             uint8_t* dst = colbuf + (size_t)(idx - b0) * p.Spad;               \
-                            if constexpr (LANEROWS) { /* RI == 4 * Gp: this thread's 16 rows are 16 */ \
-                                constexpr int TI = LANEROWS ? I : 0; /* consecutive bytes of the permuted column */ \
-                                *reinterpret_cast<uint4*>(dst + sub * 16) = make_uint4(tr[TI][0], tr[TI][1], tr[TI][2], tr[TI][3]); \
+                            if constexpr (LANEROWS) { /* this thread's 16 rows are 16 consecutive bytes */  \
+                                constexpr int TI = LANEROWS ? I : 0; /* of the column (rows past S: slack) */    \
+                                if (sub * 16u < p.S)                                            \
+                                    *reinterpret_cast<uint4*>(dst + sub * 16) = make_uint4(tr[TI][0], tr[TI][1], tr[TI][2], tr[TI][3]); \
                             } else {                                                           \
                                 _Pragma("unroll") for (int it = 0; it < RPT; it++) {           \
                                     const u32 r = sub + it * RI;                               \
                                     if (r < p.S) {                                             \
                                         const u32 ch = byte_at<I>(d[it]);                      \
                                         if (ch == '\n') bad = 1;                               \
-                                        dst[vc_pos(r, p.Gp)] = (uint8_t)ch;                    \
+                                        dst[r] = (uint8_t)ch;                                  \
                                     }                                                          \
                                 }                                                              \
                             }                                                                  \
@@ -480,7 +479,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                             for (u32 r = sub; r < p.S; r += RI) {
                                 u32 ch = f[p.row_start[r] + q + i];
                                 if (ch == '\n') bad = 1;
-                                dst[vc_pos(r, p.Gp)] = (uint8_t)ch;
+                                dst[r] = (uint8_t)ch;
                             }
                         }
                         idx++;
@@ -632,8 +631,8 @@ struct SegCells {
     const MsaView& mv; u64 a; const uint8_t* st;
     __device__ __forceinline__ u32 at(u64 c, u32 r) const
     {
-        if (st) return st[(size_t)(c - a) * mv.Spad + vc_pos(r, mv.Gp)];
-        return mv.vbit(c) ? mv.vc[mv.slot(c) * mv.Spad + vc_pos(r, mv.Gp)] : mv.ref_byte(c);
+        if (st) return st[(size_t)(c - a) * mv.Spad + r];
+        return mv.vbit(c) ? mv.vc[mv.slot(c) * mv.Spad + r] : mv.ref_byte(c);
     }
 };
 // all threads of the workgroup; returns the LDS image of the segment's columns or nullptr
@@ -1016,25 +1015,39 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
 
 // ---------------------------------------------------------------------------------------------
 // Fast path (S <= 1024): one WAVE per variant segment, rows in registers.
-//   lane holds rows lane, lane+64, ... (byte i of its 16-byte vc load = row i*64+lane), so row
-//   order = (i, lane) and consecutive ids sit in consecutive lanes.  Per-row state is SWAR bytes
-//   in a uint4: gid (group id), rm (rows not yet grouped).
-//   Grouping: rows are first grouped by RAW equality over the segment's columns ('-' and '\n'
-//   normalised to 0), which needs no per-row gap stripping; the gap-stripped string of each group
-//   is then built once, in scalar registers, from its representative.  Two raw groups with the
-//   same stripped string (same letters, different gap placement), more than KMAX groups or more
-//   than 16 columns send the segment to the generic workgroup-per-segment kernels (slow_list).
+//   vc columns are in natural row order; lane l owns rows 16l .. 16l+15 (one 16-byte load at column + 16l,
+//   byte i = row 16l+i), so row order = (lane, byte) and a lane's ids are 16 consecutive numbers.
+//   Per-row state is SWAR bytes in a uint4: gid (group id), rm (rows not yet grouped).
+//   Grouping (k_seg_group): rows are grouped by RAW equality over the segment's columns ('-' and '\n'
+//   normalised), which needs no per-row gap stripping; the gap-stripped string of each raw group is then
+//   built once from its first row, and raw groups spelling the same string are joined.  Every path is exact
+//   (msa_transforms.cpp:262-293); what the wave cannot decide exactly (NUL bytes, long strings whose hashed
+//   keys meet, more than KCAP strings) goes to the generic workgroup-per-segment kernels.
+//   The result is a grouping RECORD per segment: group id of every row (2 bits when there are at most 4
+//   strings, else 4 bits; natural row order, lane l's rows in dword(s) l), number of strings, first rows.
+//   Text (k_emit_fast): ids of rows 0..127 are placed one row per lane (mixed token lengths), ids 129.. by
+//   the lane that owns the 16 rows: per-lane cursors in LDS, one ds_add_rtn + one aligned ds_write_b32 per id.
 // ---------------------------------------------------------------------------------------------
-constexpr int KMAX = 8;
-constexpr u64 META_FAST = 1ull << 63;     // | ncol << 48 | slot of the first column
-constexpr u64 META_SCATTER = 1ull << 61;  // slots of the columns are not consecutive (tile edge)
-constexpr u64 META_SLOT = 0xffffffffffffull;
+constexpr int KCAP = 64;                  // distinct strings per fast segment (group g lives in lane g)
+constexpr u64 META_REC = 1ull << 63;      // the segment has a grouping record; low 40 bits = record index
+constexpr u64 META_KIND4 = 1ull << 62;    // 4-bit group ids (5..16 strings), else 2-bit
+constexpr u64 META_INLINE = 1ull << 61;   // the .eds text of the segment is in the record
+constexpr u64 META_KIND8 = 1ull << 60;    // 8-bit group ids (17..64 strings)
+constexpr u64 META_RECID = (1ull << 40) - 1;
+constexpr u64 CNT_SCATTER = 1ull << 63;   // count-list descriptor: ncol << 48 | slot of the first column
+constexpr u64 CNT_SLOT = (1ull << 48) - 1;
+// record header (behind the group ids): +0 u32 k | textlen << 8 | ncol << 16;  +8 u64 slot0 | CNT_SCATTER;
+// +16 u16 rep[16] (first row of every string);  +48 text[80]
+constexpr u32 REC_H_SLOT = 8, REC_H_REP = 16, REC_H_TEXT = 144, REC_TEXT_MAX = 64;   // rep[64] ends at 144
 
-// thread per segment: sizes of common segments, slot/ncol descriptor of variant segments
+// thread per segment: sizes of common segments; a variant segment of pure variant columns gets its column
+// descriptor into cnt_meta[vi] (vi = its ordinal among the variant segments = its record index) for the
+// wave-per-segment grouping kernel, the others (descriptor 0) go to the generic kernels
 __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
 {
     const MsaView& mv = p.mv;
     const u64 nseg = *p.nseg_ptr;
+    const u64 p0 = mv.vbit(0) ? 0 : 1;                   // variant and common segments alternate
     for (u64 seg = blockIdx.x * (u64)blockDim.x + threadIdx.x; seg < nseg; seg += (u64)gridDim.x * blockDim.x) {
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         if (!mv.vbit(a)) {
@@ -1043,7 +1056,8 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
             p.segmeta[seg] = 0;
             continue;
         }
-        u64 meta = 0;                                     // 0 on a variant segment: not fast
+        const u64 vi = (seg - p0) >> 1;
+        u64 cm = 0;                                       // 0: generic kernels
         const u64 ncol = b - a;
         if (ncol <= 64) {
             const u64 s0 = mv.slot(a);
@@ -1052,10 +1066,11 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
                 pure = pure && mv.vbit(c);
                 if (pure) contig = contig && mv.slot(c) == s0 + (c - a);
             }
-            if (pure) meta = META_FAST | (contig ? 0 : META_SCATTER) | (ncol << 48) | s0;
+            if (pure) cm = (ncol << 48) | s0 | (contig ? 0 : CNT_SCATTER);
         }
-        if (!meta) p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;      // too wide for the fast kernels
-        p.segmeta[seg] = meta;
+        if (!cm) p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;        // too wide or mixed columns
+        p.cnt_meta[vi] = cm;
+        p.segmeta[seg] = 0;                               // k_seg_group fills it in
     }
 }
 
@@ -1104,44 +1119,23 @@ __device__ __forceinline__ uint4 normalise_col(const uint4& c, const uint4& vmas
     return make_uint4(c.x & ~gap.x, c.y & ~gap.y, c.z & ~gap.z, c.w & ~gap.w);
 }
 
-constexpr int KCAP = 64;          // distinct strings per fast segment (group g lives in lane g)
-// Grouping record of a fast segment, written by the count kernel and read by the emit kernel
-// (so the rows are grouped once): 1024 group-id bytes in vc row order | rep[64] u16 | letter[64] u8
-// | k.  Indexed by the ordinal of the variant segment.
-constexpr u32 GREC_BYTES = 1280, GREC_REP = 1024, GREC_CHR = 1152, GREC_K = 1216;
 struct FastGroups {
-    uint4 gid;            // byte i = group of row i*64+lane (0xFF: no such row)
+    uint4 gid;            // byte i = group of row 16*lane+i (0xFF: no such row)
     u32 k;                // number of distinct strings (wave-uniform)
     u32 sumlen;           // sum of their lengths
     // lane g holds the state of group g
-    u64 key_lo, key_hi;   // ncol == 1: the letter; else 96-bit hash of the gap-stripped string
+    u64 key_lo, key_hi;   // the group's gap-stripped string (packed) or its hash, + length
     u32 rep;              // representative row (first row of the group in row order)
     u32 len;              // length of the group's string
 };
 
-// lane-private validity mask: byte i = 0xFF iff row i*64+lane exists
+// lane-private validity mask: byte i = 0xFF iff row 16*lane+i exists
 __device__ __forceinline__ uint4 fast_valid_mask(u32 lane, u32 S)
 {
-    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if ((u32)i * 64u + lane < S) w0 |= 0xffu << (i * 8);
-        if ((u32)(i + 4) * 64u + lane < S) w1 |= 0xffu << (i * 8);
-        if ((u32)(i + 8) * 64u + lane < S) w2 |= 0xffu << (i * 8);
-        if ((u32)(i + 12) * 64u + lane < S) w3 |= 0xffu << (i * 8);
-    }
-    return make_uint4(w0, w1, w2, w3);
-}
-
-// the not yet grouped row that comes first in row order (i, lane): returns i (uniform) and its lane
-__device__ __forceinline__ u32 first_remaining(const uint4& rm, int& leader)
-{
-    const u32 i0 = first_byte_index(rm);
-    u64 bl = 0;
-    u32 t = 0;
-    for (; t < 16; t++) { bl = ballot64(i0 == t); if (bl) break; }
-    leader = __builtin_ctzll(bl);
-    return t;
+    const u32 base = lane * 16u;
+    const u32 n = S > base ? (S - base < 16u ? S - base : 16u) : 0u;       // existing rows of this lane
+    auto word = [&](u32 o) -> uint32_t { return n >= o + 4u ? 0xffffffffu : (n > o ? (1u << (8u * (n - o))) - 1u : 0u); };
+    return make_uint4(word(0), word(4), word(8), word(12));
 }
 
 // assign the rows in `eq` to the group with key (klo,khi): an existing one or a new one.
@@ -1181,11 +1175,11 @@ struct FastWeights {
 };
 __device__ const FastWeights FAST_W{};
 
-// XOR of v over the 64 lanes, wave-uniform (DPP row shifts and broadcasts; lane 63 ends up with all)
 template <int CTRL, int ROWMASK> __device__ __forceinline__ u32 dpp_move0(u32 v)
 {
     return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);   // lanes without a source get 0
 }
+// XOR / OR of v over the 64 lanes, wave-uniform (DPP row shifts and broadcasts; lane 63 ends up with all)
 __device__ __forceinline__ u32 wave_xor_all(u32 v)
 {
     v ^= dpp_move0<0x111, 0xf>(v);       // row_shr:1
@@ -1196,12 +1190,22 @@ __device__ __forceinline__ u32 wave_xor_all(u32 v)
     v ^= dpp_move0<0x143, 0xc>(v);       // row_bcast:31 -> rows 2, 3
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
-
 __device__ __forceinline__ u32 wave_or_all(u32 v)
 {
     v |= dpp_move0<0x111, 0xf>(v); v |= dpp_move0<0x112, 0xf>(v); v |= dpp_move0<0x114, 0xf>(v);
     v |= dpp_move0<0x118, 0xf>(v); v |= dpp_move0<0x142, 0xa>(v); v |= dpp_move0<0x143, 0xc>(v);
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ u32 wave_scan_incl(u32 v)
+{
+    v += dpp_move0<0x111, 0xf>(v);       // row_shr:1
+    v += dpp_move0<0x112, 0xf>(v);       // row_shr:2
+    v += dpp_move0<0x114, 0xf>(v);       // row_shr:4
+    v += dpp_move0<0x118, 0xf>(v);       // row_shr:8
+    v += dpp_move0<0x142, 0xa>(v);       // row_bcast:15 -> rows 1, 3
+    v += dpp_move0<0x143, 0xc>(v);       // row_bcast:31 -> rows 2, 3
+    return v;
 }
 // minimum of v over lanes 0..7 (wave-uniform)
 __device__ __forceinline__ u32 min_lanes8(u32 v)
@@ -1213,44 +1217,54 @@ __device__ __forceinline__ u32 min_lanes8(u32 v)
     return (u32)__builtin_amdgcn_readlane((int)v, 7);
 }
 
-// One column over the alphabet {A, C, G, T, N, -}: the grouping of msa_transforms.cpp:262-293 with
-// byte-table lookups (v_perm_b32 = four lookups in an 8-entry table per instruction).
-//   class(b) = ((b >> 1) ^ (b >> 2)) & 7 :  A 0, C 1, G 2, N 4, '-' 5, T 7  (3 and 6 unused)
-// Any other byte (lower case, IUPAC codes, a stray newline) fails the reverse lookup and the caller
-// takes the general path.  Group ids are the ranks of the classes by first row; the groups' state
-// (representative row, letter) lands in lanes 0..k-1 as in fast_assign.
-__device__ __forceinline__ bool fast_group_dna1(const uint4& x, const uint4& vmask, u32 lane, FastGroups& G)
+// class code of the DNA alphabet {A, C, G, T, N, -}: class(b) = ((b >> 1) ^ (b >> 2)) & 7 :
+//   A 0, C 1, G 2, N 4, '-' 5, T 7  (3 and 6 unused).  Any other byte (lower case, IUPAC codes, NUL, a stray
+// newline) fails the reverse lookup (v_perm_b32 = four lookups in an 8-entry table per instruction).
+constexpr u32 DNA_LET_LO = 0x00474341u, DNA_LET_HI = 0x54002d4eu;      // class -> letter (0: unused class)
+__device__ __forceinline__ uint4 dna_classes(const uint4& x)
 {
-    constexpr u32 LET_LO = 0x00474341u, LET_HI = 0x54002d4eu;      // class -> letter (0: unused class)
+    return make_uint4(((x.x >> 1) ^ (x.x >> 2)) & 0x07070707u, ((x.y >> 1) ^ (x.y >> 2)) & 0x07070707u,
+                      ((x.z >> 1) ^ (x.z >> 2)) & 0x07070707u, ((x.w >> 1) ^ (x.w >> 2)) & 0x07070707u);
+}
+__device__ __forceinline__ u32 dna_bad(const uint4& x, const uint4& cls, const uint4& vmask)
+{
+    return ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.x) ^ x.x) & vmask.x) |
+           ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.y) ^ x.y) & vmask.y) |
+           ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.z) ^ x.z) & vmask.z) |
+           ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.w) ^ x.w) & vmask.w);
+}
+
+// One column over {A, C, G, T, N, -}: the grouping of msa_transforms.cpp:262-293 with byte-table lookups.
+//   rb   = the column's byte of row `lane` (rows 0..63 one per lane: most classes first appear there, and then
+//          their first row is one ballot away)
+// Group ids are the ranks of the classes by first row; group g's state lands in lane g as in fast_assign.
+__device__ __forceinline__ bool fast_group_dna1(const uint4& x, u32 rb, const uint4& vmask, u32 lane, u32 S, FastGroups& G)
+{
     constexpr u32 OH_LO = 0x08040201u, OH_HI = 0x80402010u;        // class -> 1 << class
-    uint4 cls;
-    cls.x = ((x.x >> 1) ^ (x.x >> 2)) & 0x07070707u; cls.y = ((x.y >> 1) ^ (x.y >> 2)) & 0x07070707u;
-    cls.z = ((x.z >> 1) ^ (x.z >> 2)) & 0x07070707u; cls.w = ((x.w >> 1) ^ (x.w >> 2)) & 0x07070707u;
-    const u32 bad = ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.x) ^ x.x) & vmask.x) |
-                    ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.y) ^ x.y) & vmask.y) |
-                    ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.z) ^ x.z) & vmask.z) |
-                    ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.w) ^ x.w) & vmask.w);
-    if (ballot64(bad != 0)) return false;
-    // classes present in the column
+    uint4 cls = dna_classes(x);
+    if (ballot64(dna_bad(x, cls, vmask) != 0)) return false;
+    // classes present in this lane's rows, and in the column
     u32 pl = (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.x) & vmask.x) | (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.y) & vmask.y) |
              (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.z) & vmask.z) | (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.w) & vmask.w);
-    pl |= pl >> 16; pl |= pl >> 8;
-    const u32 P = wave_or_all(pl & 0xffu);
-    cls.x |= ~vmask.x; cls.y |= ~vmask.y; cls.z |= ~vmask.z; cls.w |= ~vmask.w;   // rows that do not exist: 0xFF
-    // first row of every class: lane c keeps class c's (rows are scanned 64 at a time, in row order)
-    u32 firstv = 0xffffffffu, missing = P;
-#define EDSX_F(I)                                                                                 \
-    if (missing) {                                                                                \
-        const u32 cb = byte_at<I>(cls);                                                           \
-        for (u32 mm = missing; mm; mm &= mm - 1) {                                                \
-            const u32 c = (u32)__builtin_ctz(mm);                                                 \
-            const u64 b = ballot64(cb == c);                                                      \
-            if (b) { firstv = lane == c ? (u32)I * 64u + (u32)__builtin_ctzll(b) : firstv; missing &= ~(1u << c); } \
-        }                                                                                         \
+    pl |= pl >> 16; pl |= pl >> 8; pl &= 0xffu;
+    const u32 P = wave_or_all(pl);
+    const u32 rc = lane < S ? (((rb >> 1) ^ (rb >> 2)) & 7u) : 8u;  // class of row `lane`
+    // first row of every class: lane c keeps class c's
+    u32 firstv = 0xffffffffu;
+    for (u32 mm = P; mm; mm &= mm - 1) {
+        const u32 c = (u32)__builtin_ctz(mm);
+        const u64 b = ballot64(rc == c);
+        u32 f;
+        if (b) f = (u32)__builtin_ctzll(b);
+        else {                                             // not among the first 64 rows
+            const int L = __builtin_ctzll(ballot64(((pl >> c) & 1u) != 0));
+            uint4 e = bytes_eq_mask(cls, c * 0x01010101u);
+            e.x &= vmask.x; e.y &= vmask.y; e.z &= vmask.z; e.w &= vmask.w;
+            f = 16u * (u32)L + (u32)__builtin_amdgcn_readlane((int)first_byte_index(e), L);
+        }
+        firstv = lane == c ? f : firstv;
     }
-    EDSX_F(0) EDSX_F(1) EDSX_F(2) EDSX_F(3) EDSX_F(4) EDSX_F(5) EDSX_F(6) EDSX_F(7)
-    EDSX_F(8) EDSX_F(9) EDSX_F(10) EDSX_F(11) EDSX_F(12) EDSX_F(13) EDSX_F(14) EDSX_F(15)
-#undef EDSX_F
+    cls.x |= ~vmask.x; cls.y |= ~vmask.y; cls.z |= ~vmask.z; cls.w |= ~vmask.w;   // rows that do not exist: 0xFF
     // classes in order of first row -> group ids; table class -> group for the lookup below
     u64 lut = ~0ull;
     u32 g = 0, sumlen = 0;
@@ -1258,7 +1272,7 @@ __device__ __forceinline__ bool fast_group_dna1(const uint4& x, const uint4& vma
     for (u32 rem = P; rem; g++) {
         const u32 mn = min_lanes8(firstv);
         const u32 c = (u32)__builtin_ctzll(ballot64(lane < 8u && firstv == mn));
-        const u32 letter = c == 5u ? 0u : (u32)((((u64)LET_HI << 32) | LET_LO) >> (8u * c)) & 0xffu;
+        const u32 letter = c == 5u ? 0u : (u32)((((u64)DNA_LET_HI << 32) | DNA_LET_LO) >> (8u * c)) & 0xffu;
         lut = (lut & ~(0xffull << (8u * c))) | ((u64)g << (8u * c));
         if (lane == g) { G.key_lo = letter; G.rep = mn; G.len = letter ? 1u : 0u; }
         sumlen += letter ? 1u : 0u;
@@ -1272,117 +1286,140 @@ __device__ __forceinline__ bool fast_group_dna1(const uint4& x, const uint4& vma
     return true;
 }
 
+// the not yet grouped row that comes first in row order (lane, byte): its lane and byte index (uniform)
+__device__ __forceinline__ bool first_remaining(const uint4& rm, int& leader, u32& i0)
+{
+    const u64 b = ballot64(any4(rm));
+    if (!b) return false;
+    leader = __builtin_ctzll(b);
+    i0 = (u32)__builtin_amdgcn_readlane((int)first_byte_index(rm), leader);
+    return true;
+}
+
+// 2..20 columns over {A,C,G,T,N,-}: EXACT raw keys, 3 bits per column (class code), NK dwords of ten columns
+// per row.  Rows with equal keys are byte-identical; a raw group's gap-stripped string is read off its key
+// (drop the gap classes), so no row is re-read.  Returns 1 done, 0 another alphabet, -1 more than KCAP strings.
+template <int NK, class ColPtr>
+__device__ __forceinline__ int fast_group_dnakeys(ColPtr col_ptr, u32 ncol, const uint4& col0, u32 lane, const uint4& vmask,
+                                                  FastGroups& G)
+{
+    u32 key[NK][16];
+#pragma unroll
+    for (int n = 0; n < NK; n++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) key[n][i] = 0;
+    u32 badacc = 0;
+#define EDSX_K(I) key[n][I] |= byte_at<I>(cls) << sh;
+#pragma unroll
+    for (int n = 0; n < NK; n++) {
+        const u32 cbase = 10u * n, cend = ncol < cbase + 10u ? ncol : cbase + 10u;
+        for (u32 c0 = cbase; c0 < cend; c0 += 4) {
+            uint4 cvs[4];                              // four column loads in flight
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cvs[j] = make_uint4(0, 0, 0, 0);
+                if (c0 + j < cend) cvs[j] = (c0 + j == 0) ? col0 : load16u(col_ptr(c0 + j));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (c0 + j < cend) {
+                    const uint4 x = cvs[j];
+                    const uint4 cls = dna_classes(x);
+                    badacc |= dna_bad(x, cls, vmask);
+                    const u32 sh = 3u * (c0 + j - cbase);
+                    EDSX_K(0) EDSX_K(1) EDSX_K(2) EDSX_K(3) EDSX_K(4) EDSX_K(5) EDSX_K(6) EDSX_K(7)
+                    EDSX_K(8) EDSX_K(9) EDSX_K(10) EDSX_K(11) EDSX_K(12) EDSX_K(13) EDSX_K(14) EDSX_K(15)
+                }
+            }
+        }
+    }
+#undef EDSX_K
+    if (ballot64(badacc != 0)) return 0;
+    uint4 rm = vmask;
+    int leader;
+    u32 i0;
+    while (first_remaining(rm, leader, i0)) {
+        u32 rk[NK];
+#pragma unroll
+        for (int n = 0; n < NK; n++) {
+            u32 mk = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) mk = (i0 == (u32)i) ? key[n][i] : mk;
+            rk[n] = (u32)__builtin_amdgcn_readlane((int)mk, leader);
+        }
+        uint32_t e[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            bool same = key[0][i] == rk[0];
+            if (NK > 1) same = same && key[NK - 1][i] == rk[NK - 1];
+            if (same) e[i >> 2] |= 0xffu << ((i & 3) * 8);
+        }
+        const uint4 eq = make_uint4(e[0] & rm.x, e[1] & rm.y, e[2] & rm.z, e[3] & rm.w);
+        // the group's string: its key without the gap classes; lane = column
+        u32 cl = 5u;
+        if (lane < ncol) cl = ((lane < 10u ? rk[0] : rk[NK - 1]) >> (3u * (lane < 10u ? lane : lane - 10u))) & 7u;
+        const u64 nz = ballot64(cl != 5u);
+        const u32 len = (u32)__builtin_popcountll(nz), pos = mbcnt(nz);
+        u32 klo = 0, khi = 0;                              // 3 bits per letter, ten letters per dword
+        if (cl != 5u) { if (pos < 10u) klo = cl << (3u * pos); else khi = cl << (3u * (pos - 10u)); }
+        klo = wave_or_all(klo);
+        if (NK > 1) khi = wave_or_all(khi);
+        if (!fast_assign(G, rm, eq, ((u64)khi << 32) | klo, (u64)len << 32, len, lane, (u32)leader * 16u + i0)) return -1;
+    }
+    return 1;
+}
+
 // Group the rows of a fast segment (msa_transforms.cpp:262-293: distinct gap-stripped strings in
 // order of first appearance).  Returns false when the segment must take the generic path.
-//   one column : exact, SWAR byte compares.
-//   2..10 cols over {A,C,G,T,N,-}: exact 3-bit-per-column keys.
+//   one column : DNA table lookups, else exact SWAR byte compares.
+//   2..20 cols over {A,C,G,T,N,-}: exact 3-bit-per-column keys.
 //   otherwise  : every row gets a 96-bit additive signature of its raw column bytes (gaps normalised
 //                to 0; v_mad_u32_u24 = full rate); rows with equal signatures are PROPOSED as a raw
 //                group and then compared with the group's first row byte for byte (phase B), so the
 //                grouping is exact; raw groups that spell the same string are joined by their
 //                stripped string (verbatim key up to 12 letters; longer strings that hash alike send
 //                the segment to the generic kernels).  NUL bytes (msa_transforms.cpp:282) -> generic.
-// NR: rows per lane that can exist (16; 4 when S <= 256)
-template <bool CHECK_NL, int NR>
-__device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 meta, const uint4& col0, u32 lane,
+template <bool CHECK_NL>
+__device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 cmeta, const uint4& col0, u32 rb, u32 lane,
                                            const uint4& vmask, FastGroups& G, u32& saw_nl)
 {
-    const u32 ncol = (u32)(meta >> 48) & 0xffu;
+    const u32 ncol = (u32)(cmeta >> 48) & 0xffu;
     uint4 rm = vmask;
     G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
     G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
+    int leader;
+    u32 i0;
 
     if (ncol == 1) {
-        if (fast_group_dna1(col0, vmask, lane, G)) return true;
+        if (fast_group_dna1(col0, rb, vmask, lane, mv.S, G)) return true;
         G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
         G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
         // a NUL byte ends the row's string in the reference (msa_transforms.cpp:282): exact kernels only
         if (ballot64(any_nul(col0, vmask))) return false;
         const uint4 col = normalise_col<CHECK_NL>(col0, vmask, saw_nl);
-        while (ballot64(any4(rm))) {
-            int leader;
-            const u32 i0 = first_remaining(rm, leader);
+        while (first_remaining(rm, leader, i0)) {
             const u32 c = leader_byte(col, leader, i0);
             uint4 eq = bytes_eq_mask(col, c * 0x01010101u);
             eq.x &= rm.x; eq.y &= rm.y; eq.z &= rm.z; eq.w &= rm.w;
-            if (!fast_assign(G, rm, eq, (u64)c, 0ull, c ? 1u : 0u, lane, i0 * 64u + (u32)leader)) return false;
+            if (!fast_assign(G, rm, eq, (u64)c, 0ull, c ? 1u : 0u, lane, (u32)leader * 16u + i0)) return false;
         }
         return true;
     }
 
-    const u64 slot0 = meta & META_SLOT;
-    const bool scatter = (meta & META_SCATTER) != 0;
-    const uint8_t* cbase = mv.vc + slot0 * (u64)mv.Spad + (u64)lane * mv.Gp;
+    const u64 slot0 = cmeta & CNT_SLOT;
+    const bool scatter = (cmeta & CNT_SCATTER) != 0;
+    const u32 loff = lane * 16u < mv.Spad - 16u ? lane * 16u : mv.Spad - 16u;     // lanes without rows stay inside the column
+    const uint8_t* cbase = mv.vc + slot0 * (u64)mv.Spad + loff;
     auto col_ptr = [&](u32 c) -> const uint8_t* {
-        return scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + (u64)lane * mv.Gp : cbase + (u64)c * mv.Spad;
+        return scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + loff : cbase + (u64)c * mv.Spad;
     };
 
-    // ---- up to 10 columns over {A,C,G,T,N,-}: EXACT raw keys, 3 bits per column (class code of
-    // fast_group_dna1), one dword per row.  Rows with equal keys are byte-identical; a raw group's
-    // gap-stripped string is read off its key (drop the gap classes), so no row is re-read.
-    if (ncol <= 10u) {
-        constexpr u32 LET_LO = 0x00474341u, LET_HI = 0x54002d4eu;
-        u32 key[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) key[i] = 0;
-        u32 badacc = 0;
-#define EDSX_K(I) if constexpr (I < NR) key[I] |= byte_at<I>(cls) << sh;
-        for (u32 c0 = 0; c0 < ncol; c0 += 4) {
-            uint4 cvs[4];                              // four column loads in flight
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                cvs[j] = make_uint4(0, 0, 0, 0);
-                if (c0 + j < ncol) cvs[j] = (c0 + j == 0) ? col0 : load16u(col_ptr(c0 + j));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (c0 + j < ncol) {
-                    const uint4 x = cvs[j];
-                    uint4 cls;
-                    cls.x = ((x.x >> 1) ^ (x.x >> 2)) & 0x07070707u; cls.y = ((x.y >> 1) ^ (x.y >> 2)) & 0x07070707u;
-                    cls.z = ((x.z >> 1) ^ (x.z >> 2)) & 0x07070707u; cls.w = ((x.w >> 1) ^ (x.w >> 2)) & 0x07070707u;
-                    badacc |= ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.x) ^ x.x) & vmask.x) |
-                              ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.y) ^ x.y) & vmask.y) |
-                              ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.z) ^ x.z) & vmask.z) |
-                              ((__builtin_amdgcn_perm(LET_HI, LET_LO, cls.w) ^ x.w) & vmask.w);
-                    const u32 sh = 3u * (c0 + j);
-                    EDSX_K(0) EDSX_K(1) EDSX_K(2) EDSX_K(3) EDSX_K(4) EDSX_K(5) EDSX_K(6) EDSX_K(7)
-                    EDSX_K(8) EDSX_K(9) EDSX_K(10) EDSX_K(11) EDSX_K(12) EDSX_K(13) EDSX_K(14) EDSX_K(15)
-                }
-            }
-        }
-#undef EDSX_K
-        if (!ballot64(badacc != 0)) {
-            while (ballot64(any4(rm))) {
-                int leader;
-                const u32 i0 = first_remaining(rm, leader);
-                u32 mk = 0;
-#pragma unroll
-                for (int i = 0; i < NR; i++) mk = (i0 == (u32)i) ? key[i] : mk;
-                const u32 rk = (u32)__builtin_amdgcn_readlane((int)mk, leader);
-                uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (key[i] == rk) e0 |= 0xffu << (i * 8);
-                    if constexpr (NR > 4) {
-                        if (key[i + 4] == rk) e1 |= 0xffu << (i * 8);
-                        if (key[i + 8] == rk) e2 |= 0xffu << (i * 8);
-                        if (key[i + 12] == rk) e3 |= 0xffu << (i * 8);
-                    }
-                }
-                const uint4 eq = make_uint4(e0 & rm.x, e1 & rm.y, e2 & rm.z, e3 & rm.w);
-                // the group's string: its key without the gap classes (wave-uniform scalar work)
-                u64 sk = 0;
-                u32 len = 0;
-                for (u32 c = 0; c < ncol; c++) {
-                    const u32 cl = (rk >> (3u * c)) & 7u;
-                    if (cl != 5u) { sk |= (u64)cl << (3u * len); len++; }
-                }
-                if (!fast_assign(G, rm, eq, sk, (u64)len << 32, len, lane, i0 * 64u + (u32)leader)) return false;
-            }
-            return true;
-        }
-        rm = vmask;                                    // another alphabet: the signature path below
+    if (ncol <= 20u) {
+        const int r = ncol <= 10u ? fast_group_dnakeys<1>(col_ptr, ncol, col0, lane, vmask, G)
+                                  : fast_group_dnakeys<2>(col_ptr, ncol, col0, lane, vmask, G);
+        if (r) return r > 0;
+        G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);          // another alphabet: the signature path below
+        G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
     }
 
     // ---- phase A: raw signatures of the 16 rows of this lane: sig_j(row) = sum_c byte(row,c) * W_j(c)
@@ -1424,12 +1461,10 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
 #pragma unroll
     for (int i = 0; i < 16; i++) { h1[i] &= 1u; h2[i] = 0; h3[i] = 0; }
 #endif
-    // ---- phase B: raw groups in order of first appearance; each is keyed by a 96-bit hash of its
-    // representative's gap-stripped string (+ length), so that raw groups spelling the same string
-    // (same letters, other gap placement) fall together in fast_assign
-    while (ballot64(any4(rm))) {
-        int leader;
-        const u32 i0 = first_remaining(rm, leader);
+    // ---- phase B: raw groups in order of first appearance; each is keyed by its first row's gap-stripped
+    // string (+ length), so that raw groups spelling the same string (same letters, other gap placement)
+    // fall together in fast_assign
+    while (first_remaining(rm, leader, i0)) {
         u32 m1 = 0, m2 = 0, m3 = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -1437,15 +1472,11 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
         }
         const u32 r1 = (u32)__builtin_amdgcn_readlane((int)m1, leader), r2 = (u32)__builtin_amdgcn_readlane((int)m2, leader);
         const u32 r3 = (u32)__builtin_amdgcn_readlane((int)m3, leader);
-        uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+        uint32_t e[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (h1[i] == r1 && h2[i] == r2 && h3[i] == r3) e0 |= 0xffu << (i * 8);
-            if (h1[i + 4] == r1 && h2[i + 4] == r2 && h3[i + 4] == r3) e1 |= 0xffu << (i * 8);
-            if (h1[i + 8] == r1 && h2[i + 8] == r2 && h3[i + 8] == r3) e2 |= 0xffu << (i * 8);
-            if (h1[i + 12] == r1 && h2[i + 12] == r2 && h3[i + 12] == r3) e3 |= 0xffu << (i * 8);
-        }
-        const uint4 eq = make_uint4(e0 & rm.x, e1 & rm.y, e2 & rm.z, e3 & rm.w);
+        for (int i = 0; i < 16; i++)
+            if (h1[i] == r1 && h2[i] == r2 && h3[i] == r3) e[i >> 2] |= 0xffu << ((i & 3) * 8);
+        const uint4 eq = make_uint4(e[0] & rm.x, e[1] & rm.y, e[2] & rm.z, e[3] & rm.w);
         // The signature only proposes the group: every member is now compared with the leader byte for
         // byte over all columns (gaps normalised as above).  A mismatch is a signature collision: the
         // segment goes to the generic kernels, which compare rows exactly.
@@ -1460,11 +1491,11 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
             if (ballot64(mism != 0)) return false;
         }
         // the representative's string: lane = column
-        const u32 rep_row = i0 * 64u + (u32)leader;
+        const u32 rep_row = (u32)leader * 16u + i0;
         u32 ch = 0;
         if (lane < ncol) {
             const u64 sl = scatter ? mv.slot(seg_a + lane) : slot0 + lane;
-            ch = mv.vc[sl * (u64)mv.Spad + vc_pos(rep_row, mv.Gp)];
+            ch = mv.vc[sl * (u64)mv.Spad + rep_row];
             if (ch == '-' || ch == '\n') ch = 0;
         }
         const u64 nzm = ballot64(ch != 0);
@@ -1500,19 +1531,22 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 met
     return true;
 }
 
-__device__ __forceinline__ u32 packed_len(u64 k) { return k ? (u32)(71 - __builtin_clzll(k)) >> 3 : 0u; }
-
-__device__ __forceinline__ uint4 fast_load_col(const MsaView& mv, u64 meta, u32 lane)
+// group-id bytes of this lane's 16 rows -> 2 bits per row (ids 0..3; rows that do not exist: 0)
+__device__ __forceinline__ u32 pack_gid2(const uint4& gid, const uint4& vmask)
 {
-    if (!(meta & META_FAST)) return make_uint4(0, 0, 0, 0);
-    return load16u(mv.vc + (meta & META_SLOT) * (u64)mv.Spad + (u64)lane * mv.Gp);
+    auto p = [](uint32_t x) -> u32 { x &= 0x03030303u; x |= x >> 6; x |= x >> 12; return x & 0xffu; };
+    return p(gid.x & vmask.x) | (p(gid.y & vmask.y) << 8) | (p(gid.z & vmask.z) << 16) | (p(gid.w & vmask.w) << 24);
+}
+// ... -> 4 bits per row (ids 0..15): rows 0..7 in .x, 8..15 in .y
+__device__ __forceinline__ uint2 pack_gid4(const uint4& gid, const uint4& vmask)
+{
+    auto p = [](uint32_t x) -> u32 { x &= 0x0f0f0f0fu; x |= x >> 4; return (x & 0xffu) | ((x >> 8) & 0xff00u); };
+    return make_uint2(p(gid.x & vmask.x) | (p(gid.y & vmask.y) << 16), p(gid.z & vmask.z) | (p(gid.w & vmask.w) << 16));
 }
 
-
-// K3 fast: sizes of the variant segments.  Variant and common segments alternate, so the
-// variant ones are seg = 2*vi + p0.
-template <int NR>
-__global__ void __launch_bounds__(256, 4) k_seg_count_fast(FastParams p)
+// K3 fast: grouping records + sizes of the variant segments with a column descriptor, one wave per segment.
+// The descriptor and the first column of the wave's next segment are requested one iteration ahead.
+__global__ void __launch_bounds__(256, 4) k_seg_group(FastParams p)
 {
     const MsaView& mv = p.mv;
     if (mv.hdr->status) return;
@@ -1522,481 +1556,444 @@ __global__ void __launch_bounds__(256, 4) k_seg_count_fast(FastParams p)
     const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
     const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
     const uint4 vmask = fast_valid_mask(lane, mv.S);
+    const u32 nl = (mv.S + 15u) >> 4;                          // lanes that own rows
+    const u32 loff = lane * 16u < mv.Spad - 16u ? lane * 16u : mv.Spad - 16u;
     u32 saw_nl = 0;
-    // everything indexed by the segment is wave-uniform: say so (readfirstlane), or hipcc predicates
-    // every use per lane and serialises the column loads
+    auto load_col = [&](u64 cm) -> uint4 {
+        return cm ? load16u(mv.vc + (cm & CNT_SLOT) * (u64)mv.Spad + loff) : make_uint4(0, 0, 0, 0);
+    };
+    auto load_rb = [&](u64 cm) -> u32 {                        // the first column's byte of row `lane`
+        return cm && lane < mv.S ? (u32)mv.vc[(cm & CNT_SLOT) * (u64)mv.Spad + lane] : 0u;
+    };
     u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + uniform32(threadIdx.x >> 6);
-    u64 meta = vi < nvs ? uniform64(p.segmeta[2 * vi + p0]) : 0;
-    u64 meta_n = vi + nw < nvs ? uniform64(p.segmeta[2 * (vi + nw) + p0]) : 0;
-    uint4 col = fast_load_col(mv, meta, lane);
+    u64 cmeta = vi < nvs ? uniform64(p.cnt_meta[vi]) : 0;
+    u64 cmeta_n = vi + nw < nvs ? uniform64(p.cnt_meta[vi + nw]) : 0;
+    uint4 col = load_col(cmeta);
+    u32 rb = load_rb(cmeta);
     while (vi < nvs) {
         const u64 seg = 2 * vi + p0;
         // prefetch: next segment's first column and the descriptor after it
-        const uint4 col_n = fast_load_col(mv, meta_n, lane);
-        const u64 meta_v = p.segmeta[2 * (vi + 2 * nw < nvs ? vi + 2 * nw : vi) + p0];   // scalar after the wait below
-
-        bool fast = (meta & META_FAST) != 0;
-        FastGroups G;
-        if (fast) fast = fast_group<true, NR>(mv, (meta & META_SCATTER) ? uniform64(p.seg_start[seg]) : 0, meta, col, lane, vmask, G, saw_nl);
-        uint8_t* rec = p.grec + vi * (u64)GREC_BYTES;
-        // wait for the prefetched column here, before this segment's stores are queued behind it
-        // (vmcnt retires in issue order: see k_emit_variant_fast)
-        asm volatile("" :: "v"(col_n.x), "v"(col_n.y), "v"(col_n.z), "v"(col_n.w), "v"(meta_v));
-        const u64 meta_nn = vi + 2 * nw < nvs ? uniform64(meta_v) : 0;
-        if (fast) {
-            *reinterpret_cast<uint4*>(rec + lane * 16u) = G.gid;
-            if (lane < G.k) {
-                *reinterpret_cast<uint16_t*>(rec + GREC_REP + lane * 2u) = (uint16_t)G.rep;
-                rec[GREC_CHR + lane] = (uint8_t)G.key_lo;
+        const uint4 col_n = load_col(cmeta_n);
+        const u32 rb_n = load_rb(cmeta_n);
+        const u64 cm_v = p.cnt_meta[vi + 2 * nw < nvs ? vi + 2 * nw : vi];      // scalar after the wait below
+        if (cmeta) {
+            const u32 ncol = (u32)(cmeta >> 48) & 0xffu;
+            FastGroups G;
+            const bool ok = fast_group<true>(mv, (cmeta & CNT_SCATTER) ? uniform64(p.seg_start[seg]) : 0, cmeta, col, rb, lane, vmask, G, saw_nl);
+            // wait for the prefetched column here, before this segment's stores are queued behind it
+            // (vmcnt retires in issue order)
+            asm volatile("" :: "v"(col_n.x), "v"(col_n.y), "v"(col_n.z), "v"(col_n.w), "v"(rb_n), "v"(cm_v));
+            if (ok) {
+                uint8_t* rec = p.rec + vi * (u64)p.rec_stride;
+                if (lane < nl) {
+                    if (G.k <= 4u) *reinterpret_cast<u32*>(rec + lane * 4u) = pack_gid2(G.gid, vmask);
+                    else if (G.k <= 16u) *reinterpret_cast<uint2*>(rec + lane * 8u) = pack_gid4(G.gid, vmask);
+                    else *reinterpret_cast<uint4*>(rec + lane * 16u) = G.gid;
+                }
+                uint8_t* hdr = rec + p.rec_gid;
+                if (lane < G.k) *reinterpret_cast<uint16_t*>(hdr + REC_H_REP + lane * 2u) = (uint16_t)G.rep;
+                if (lane == 0) {
+                    *reinterpret_cast<u32*>(hdr) = G.k | (ncol << 16);
+                    *reinterpret_cast<u64*>(hdr + REC_H_SLOT) = cmeta & (CNT_SLOT | CNT_SCATTER);
+                    p.eds_len[seg] = 2 + (u64)(G.k - 1) + G.sumlen;
+                    p.seds_len[seg] = (u64)G.k + p.tok_total;
+                    p.segmeta[seg] = META_REC | (G.k > 16u ? META_KIND8 : G.k > 4u ? META_KIND4 : 0) | vi;
+                }
+            } else if (lane == 0) {
+                p.slow_list2[atomicAdd(p.slow_count2, 1ull)] = seg;       // the generic kernels take it
             }
-            if (lane == 0) {
-                rec[GREC_K] = (uint8_t)G.k;
-                p.eds_len[seg] = 2 + (u64)(G.k - 1) + G.sumlen;
-                p.seds_len[seg] = (u64)G.k + p.tok_total;
-            }
-        } else if (lane == 0) {
-            rec[GREC_K] = 0;                              // not a fast segment
-            if (meta & META_FAST) p.slow_list2[atomicAdd(p.slow_count2, 1ull)] = seg;   // gave up: too many strings
         }
-        vi += nw; meta = meta_n; meta_n = meta_nn; col = col_n;
+        const u64 cmeta_nn = vi + 2 * nw < nvs ? uniform64(cm_v) : 0;
+        vi += nw; cmeta = cmeta_n; cmeta_n = cmeta_nn; col = col_n; rb = rb_n;
     }
     if (saw_nl) atomicOr(&mv.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));
 }
 
 // ---- K5 fast: .seds / .eds text of the variant segments.  msa_transforms.cpp:297-317.
-//   LDS per workgroup: token table tok[1024] (u64: "ddd," + length in byte 7) | per-wave staging.
-//   Ids of block i (rows i*64 .. i*64+63) are i*64+1 .. i*64+64: 3 digits for blocks 2..14; the
-//   digit count changes inside block 0 (ids 1-9 | 10-64), block 1 (65-99 | 100-128) and block 15
-//   (961-999 | 1000-1024): there the lanes below SHORT have the shorter token.
-constexpr int FAST_STAGE = 4608;   // >= 16 + KCAP + tokens of 1024 rows (4013 + 250 + 16), multiple of 256
+constexpr int EM_STAGE = 4608;     // >= tokens of 1024 rows (4013) + 16 braces + 6 bytes of padding per string
+constexpr int EM_TRASH = 256;      // one dword per lane behind it: where the tokens of rows that are not placed go
+template <int ROWS> struct EmitWaveLdsT {
+    alignas(16) uint8_t stage[EM_STAGE + EM_TRASH];   // the segment's id lists, one 4-aligned region per string
+    alignas(16) u32 tab[ROWS * 64];        // [string][lane] (bank = lane: conflict-free): where this lane's next id of that
+                                           // string goes (byte offset in stage); last row (4 / 16): dummies
+    alignas(16) u32 gt[64];                // per string: [0..15] start of its ids, [16..31] start of the ids >= 129,
+};                                         // [32..47] / [48..63] LDS source / global destination of its full 16-byte chunks
 
-template <int I> struct IdBlock {
-    static constexpr u32 TLMIN = I == 0 ? 2u : (I == 1 ? 3u : 4u);
-    static constexpr bool MIXED = I == 0 || I == 1 || I == 15;
-    static constexpr u64 SHORT = I == 0 ? ((1ull << 9) - 1) : (I == 1 ? ((1ull << 35) - 1) : (I == 15 ? ((1ull << 39) - 1) : ~0ull));
-};
-
-__device__ __forceinline__ u32 gid_byte(const uint4& gid, u32 i)       // i is wave-uniform
-{
-    const u32 w = i < 8 ? (i < 4 ? gid.x : gid.y) : (i < 12 ? gid.z : gid.w);
-    return (w >> ((i & 3) * 8)) & 0xffu;
-}
-
-// one block of 64 rows: where does this lane's token go, and advance the group cursors.
-//   cursors: registers (K compile-time, <= 4) ...
-template <int K, bool MIXED>
-__device__ __forceinline__ u32 block_offsets(u32 gi, u32 (&cur)[4], u32 tlmin, u64 shortm)
-{
-    u32 off = 0;
-#pragma unroll
-    for (int g = 0; g < K; g++) {
-        const u64 m = ballot64(gi == (u32)g);
-        u32 pre = mbcnt(m) * tlmin;
-        u32 tot = (u32)__builtin_popcountll(m) * tlmin;
-        if (MIXED) { pre += mbcnt(m & ~shortm); tot += (u32)__builtin_popcountll(m & ~shortm); }
-        off = (gi == (u32)g) ? cur[g] + pre : off;
-        cur[g] += tot;
-    }
-    return off;
-}
-//   ... or lane g's register cur_l (K run-time)
-template <bool MIXED>
-__device__ __forceinline__ u32 block_offsets_dyn(u32 gi, u32 k, u32& cur_l, u32 tlmin, u64 shortm, u32 lane)
-{
-    u32 off = 0;
-    for (u32 g = 0; g < k; g++) {
-        const u64 m = ballot64(gi == g);
-        if (!m) continue;
-        const u32 c = (u32)__builtin_amdgcn_readlane((int)cur_l, (int)g);
-        u32 pre = mbcnt(m) * tlmin;
-        u32 tot = (u32)__builtin_popcountll(m) * tlmin;
-        if (MIXED) { pre += mbcnt(m & ~shortm); tot += (u32)__builtin_popcountll(m & ~shortm); }
-        off = (gi == g) ? c + pre : off;
-        cur_l = (lane == g) ? c + tot : cur_l;
-    }
-    return off;
-}
-
-// Token bytes -> LDS as single-byte stores.  Written in C (d[0] = ..; d[1] = ..) hipcc fuses the four
-// stores into one ds_write_b32 at an unaligned address, which the LDS executes ~10x slower
-// (SQ_LDS_IDX_ACTIVE: 28 cycles per instruction).  a = LDS byte address.
+// Token bytes -> LDS as single-byte stores.  Written in C (d[0] = ..; d[1] = ..) hipcc fuses the stores into one
+// ds_write_b32 at an unaligned address, which the LDS executes ~10x slower.  a = LDS byte address.
 __device__ __forceinline__ void lds_put2(u32 a, u32 t)
 {
     const u32 t8 = t >> 8;
     asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1" :: "v"(a), "v"(t), "v"(t8) : "memory");
 }
-__device__ __forceinline__ void lds_put4(u32 a, u32 t)
-{
-    const u32 t8 = t >> 8;          // d16_hi stores bits 23:16: bytes 2 and 3 need no further shifts
-    asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\t"
-                 "ds_write_b8_d16_hi %0, %1 offset:2\n\tds_write_b8_d16_hi %0, %2 offset:3"
-                 :: "v"(a), "v"(t), "v"(t8) : "memory");
-}
 template <int OFF> __device__ __forceinline__ void lds_put1(u32 a, u32 v)
 {
     asm volatile("ds_write_b8 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
 }
-template <bool MIXED>
-__device__ __forceinline__ void write_token(uint8_t* dst, u64 t)
+__device__ __forceinline__ u32 lane_read(u32 v, u32 src_lane)       // v of lane src_lane (per-lane source)
 {
-    const u32 a = (u32)(uintptr_t)dst;    // LDS byte address (low half of the flat address)
-    if (!MIXED) { lds_put4(a, (u32)t); return; }
-    const u32 tl = (u32)(t >> 56);
-    lds_put2(a, (u32)t);
-    if (tl >= 3) lds_put1<2>(a, (u32)(t >> 16));
-    if (tl >= 4) lds_put1<3>(a, (u32)(t >> 24));
-    if (tl >= 5) lds_put1<4>(a, (u32)(t >> 32));
+    return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+__device__ __forceinline__ void store16u(uint8_t* p, const uint4& v)   // 16 bytes to an arbitrarily aligned address
+{
+    U128u t{v.x, v.y, v.z, v.w};
+    __builtin_memcpy(p, &t, 16);
 }
 
-// Writes the id lists of the k groups into `text`; returns the number of bytes (= k + tokens).
-// K > 0: compile-time group count with cursors in registers; K == 0: run-time k (<= 64), the
-// cursor of group g lives in lane g.
-template <int K>
-__device__ __forceinline__ u32 fast_emit_ids(const uint4& gid, u32 k, uint8_t* text, const u64* tok_sh, u32 lane)
+// Writes the id lists "{i,i,..}{i,..}.." of k (<= 4 / <= 16) strings of one segment to gseds (msa_transforms.cpp:305-316)
+// and returns their bytes.
+//   BITS   2: x0 = this lane's 16 group ids (2 bits each);  4: x0 = rows 0..7, x1 = rows 8..15 (4 bits each)
+//   am     bit j: row 16*lane+j (>= 128) is placed;  g0/v0, g1/v1: group id / "is placed" of rows `lane`, `64 + lane`
+//   rows 0..127 (ids 1..128: 2-, 3- and 4-byte tokens) are placed one row per lane: per block of 64 rows ONE packed
+//   DPP wave scan ranks the rows of four strings at once (the token lengths added into 8-bit fields).
+//   rows 128.. (4-byte tokens up to id 999): the owning lane walks its 16 rows; its cursor of every string lives
+//   in LDS (tab): 16 returning ds_add hand out the positions and advance the cursors, then 16 aligned ds_write_b32
+//   place the tokens (rows that are not placed use a dummy cursor: no branches, all 16 atomics in flight together).
+//   Every string's region of `stage` is padded so that its 4-byte tokens are dword-aligned; the regions are copied
+//   out one by one (16-byte LDS reads, unaligned 16-byte global stores, byte stores for the ragged ends).
+template <int BITS, bool HAS5, class Lds, class PreFlush>
+__device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, bool v0, bool v1, u32 k, u32 S, u32 lane,
+                                        const u32 (&tokc)[16], u32 htok0, u32 htok1, Lds& L, uint8_t* gseds,
+                                        PreFlush pre_flush, u32 dbg = 0)
 {
-    u32 cur[4] = {0, 0, 0, 0};
-    u32 cur_l = 0, gstart_l = 0;
-    // pass 1: bytes per group
-    if (K) {
-        block_offsets<K, true>(gid_byte(gid, 0), cur, IdBlock<0>::TLMIN, IdBlock<0>::SHORT);
-        block_offsets<K, true>(gid_byte(gid, 1), cur, IdBlock<1>::TLMIN, IdBlock<1>::SHORT);
-        for (u32 i = 2; i < 15; i++) block_offsets<K, false>(gid_byte(gid, i), cur, 4u, ~0ull);
-        block_offsets<K, true>(gid_byte(gid, 15), cur, IdBlock<15>::TLMIN, IdBlock<15>::SHORT);
+    constexpr u32 K = BITS == 2 ? 4u : 16u;        // table rows in use (row K: dummies)
+    constexpr int NQ = BITS == 2 ? 1 : 4;          // quartets of strings
+    const u32 sbase = (u32)(uintptr_t)L.stage;     // LDS byte address (low half of the flat address)
+    const u32 tl0 = lane < 9u ? 2u : 3u, tl1 = lane < 35u ? 3u : 4u;       // ids 1-9 | 10-64 and 65-99 | 100-128
+    u32 ex0 = 0, ex1 = 0;            // bytes of this lane's string in front of this lane's token, inside the block
+    u32 tot0[NQ], tot1[NQ];          // bytes per string and block, four 8-bit fields per quartet (uniform)
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        tot0[q] = 0; tot1[q] = 0;
+        if ((u32)q * 4u < k) {
+            const bool in0 = v0 && (BITS == 2 || (g0 >> 2) == (u32)q), in1 = v1 && (BITS == 2 || (g1 >> 2) == (u32)q);
+            const u32 f0 = in0 ? tl0 << ((g0 & 3u) * 8u) : 0u, f1 = in1 ? tl1 << ((g1 & 3u) * 8u) : 0u;
+            const u32 i0 = wave_scan_incl(f0), i1 = wave_scan_incl(f1);
+            if (in0) ex0 = ((i0 - f0) >> ((g0 & 3u) * 8u)) & 0xffu;
+            if (in1) ex1 = ((i1 - f1) >> ((g1 & 3u) * 8u)) & 0xffu;
+            tot0[q] = (u32)__builtin_amdgcn_readlane((int)i0, 63);
+            tot1[q] = (u32)__builtin_amdgcn_readlane((int)i1, 63);
+        }
+    }
+    // rows with ids >= 1000 (five bytes) among this lane's rows: bit j
+    const u32 first5 = 999u > lane * 16u ? 999u - lane * 16u : 0u;
+    const u32 m5 = HAS5 ? (first5 >= 16u ? 0u : (0xffffu << first5) & 0xffffu) : 0u;
+    // ---- rows 128..: bytes of every string among this lane's rows, prefix over the lanes, totals
+    u32 pre[K];                      // bytes of string g in the lanes before this one (rows >= 128)
+    u32 bbt[BITS == 2 ? 2 : 8];      // totals, two 16-bit fields per dword (uniform)
+    if (BITS == 2) {
+        // spread the row masks to the 2-bit fields
+        auto spread = [](u32 m) -> u32 { m = (m | (m << 8)) & 0x00ff00ffu; m = (m | (m << 4)) & 0x0f0f0f0fu;
+                                         m = (m | (m << 2)) & 0x33333333u; return (m | (m << 1)) & 0x55555555u; };
+        const u32 vm = spread(am);
+        const u32 lo = x0 & 0x55555555u, hi = (x0 >> 1) & 0x55555555u;
+        const u32 m[4] = {vm & ~(lo | hi), lo & ~hi & vm, hi & ~lo & vm, lo & hi & vm};
+        u32 c[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) c[g] = 4u * (u32)__builtin_popcount(m[g]);
+        if (HAS5) {
+            const u32 s5 = spread(m5);
+#pragma unroll
+            for (int g = 0; g < 4; g++) c[g] += (u32)__builtin_popcount(m[g] & s5);
+        }
+        const u32 p01 = c[0] | (c[1] << 16), p23 = c[2] | (c[3] << 16);
+        const u32 s01 = wave_scan_incl(p01), s23 = wave_scan_incl(p23);
+        const u32 e01 = s01 - p01, e23 = s23 - p23;
+        pre[0] = e01 & 0xffffu; pre[1] = e01 >> 16; pre[2] = e23 & 0xffffu; pre[3] = e23 >> 16;
+        bbt[0] = (u32)__builtin_amdgcn_readlane((int)s01, 63);
+        bbt[1] = (u32)__builtin_amdgcn_readlane((int)s23, 63);
     } else {
-        block_offsets_dyn<true>(gid_byte(gid, 0), k, cur_l, IdBlock<0>::TLMIN, IdBlock<0>::SHORT, lane);
-        block_offsets_dyn<true>(gid_byte(gid, 1), k, cur_l, IdBlock<1>::TLMIN, IdBlock<1>::SHORT, lane);
-        for (u32 i = 2; i < 15; i++) block_offsets_dyn<false>(gid_byte(gid, i), k, cur_l, 4u, ~0ull, lane);
-        block_offsets_dyn<true>(gid_byte(gid, 15), k, cur_l, IdBlock<15>::TLMIN, IdBlock<15>::SHORT, lane);
-    }
-    // group starts
-    u32 run = 0;
-    u32 gstart[4] = {0, 0, 0, 0};
-    if (K) {
 #pragma unroll
-        for (int g = 0; g < K; g++) { const u32 t = cur[g]; gstart[g] = run; cur[g] = run + 1; run += 1 + t; }
-    } else {
-        const u32 mine = lane < k ? 1u + cur_l : 0u;      // bytes of group `lane`
-        u32 incl = mine;
-        for (int o = 1; o < 64; o <<= 1) { u32 a = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += a; }
-        gstart_l = incl - mine;
-        cur_l = gstart_l + 1;
-        run = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-    }
-    // pass 2: tokens, all lanes active, exact-length LDS writes
-#define EDSX_BLK(I, MIXED_)                                                                       \
-    {                                                                                             \
-        const u32 gi = gid_byte(gid, I);                                                          \
-        const u32 off = K ? block_offsets<K, MIXED_>(gi, cur, MIXED_ ? IdBlock<(I) & 15>::TLMIN : 4u, \
-                                                     MIXED_ ? IdBlock<(I) & 15>::SHORT : ~0ull)   \
-                          : block_offsets_dyn<MIXED_>(gi, k, cur_l, MIXED_ ? IdBlock<(I) & 15>::TLMIN : 4u, \
-                                                      MIXED_ ? IdBlock<(I) & 15>::SHORT : ~0ull, lane); \
-        if (gi != 0xffu) write_token<MIXED_>(text + off, tok_sh[(I) * 64u + lane]);               \
-    }
-    EDSX_BLK(0, true)
-    EDSX_BLK(1, true)
-    for (u32 i = 2; i < 15; i++) {
-        const u32 gi = gid_byte(gid, i);
-        const u32 off = K ? block_offsets<K, false>(gi, cur, 4u, ~0ull) : block_offsets_dyn<false>(gi, k, cur_l, 4u, ~0ull, lane);
-        if (gi != 0xffu) write_token<false>(text + off, tok_sh[i * 64u + lane]);
-    }
-    EDSX_BLK(15, true)
-#undef EDSX_BLK
-    // braces (after the tokens: the closing one replaces the last ',')
-    if (K) {
-        if (lane == 0) {
+        for (int g = 0; g < 16; g++) L.tab[g * 64 + lane] = 0;
 #pragma unroll
-            for (int g = 0; g < K; g++) { text[gstart[g]] = '{'; text[cur[g] - 1] = '}'; }
+        for (int j = 0; j < 16; j++) {
+            const bool act = (am & (1u << j)) != 0;
+            const u32 g = ((j < 8 ? x0 : x1) >> (4u * (j & 7))) & 15u;
+            const u32 inc = act ? ((m5 >> j) & 1u ? 5u : 4u) : 0u;
+            atomicAdd(&L.tab[(act ? g : 16u) * 64u + lane], inc);
         }
-    } else if (lane < k) { text[gstart_l] = '{'; text[cur_l - 1] = '}'; }
-    return run;
-}
-
-// ---- id lists: packed prefix sums per block of 64 rows, four groups at a time ----------------------
-// Lane `lane` owns rows lane, lane+64, ... (block i = rows i*64 .. i*64+63), exactly as the group ids
-// arrive.  The members of a group inside one block are adjacent in the output, so the lanes of a
-// block store to consecutive LDS addresses (no bank conflicts beyond the overlap of the k groups).
-// Per block one DPP wave scan ranks the rows of ALL groups at once: every lane adds its weight into
-// the 8-bit field of its group (4 groups per dword).  The weight is 1 in the blocks whose ids all
-// have 3 digits (rank*4 = bytes) and the token length in blocks 0 and 1, whose ids have 1-2 / 2-3
-// digits (64 tokens of <= 3 bytes and 35*3 + 29*4 bytes both stay below 256).  Block 15 (ids
-// 961..1024, up to 281 bytes) is scanned with 16-bit fields.  Rows that do not exist weigh 0, so
-// every block is processed unconditionally: straight-line code whose independent scans interleave.
-//   wv    byte i: weight of row i*64+lane (0: no such row)          -- lane constant
-//   tokc  [i]: the first four bytes of that row's token "ddd,"      -- lane constant
-__device__ __forceinline__ u32 dpp_add(u32 v, u32 moved) { return v + moved; }
-template <int CTRL, int ROWMASK> __device__ __forceinline__ u32 dpp_take(u32 v)
-{
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);   // lanes without a source get 0
-}
-__device__ __forceinline__ u32 wave_scan_incl(u32 v)
-{
-    v += dpp_take<0x111, 0xf>(v);        // row_shr:1
-    v += dpp_take<0x112, 0xf>(v);        // row_shr:2
-    v += dpp_take<0x114, 0xf>(v);        // row_shr:4
-    v += dpp_take<0x118, 0xf>(v);        // row_shr:8
-    v += dpp_take<0x142, 0xa>(v);        // row_bcast:15 -> rows 1, 3
-    v += dpp_take<0x143, 0xc>(v);        // row_bcast:31 -> rows 2, 3
-    return v;
-}
-
-// Up to four groups (ids 0..3 in `gid`; rows with weight 0 in `wv` are not placed).  Group g's list
-// starts at text + run0 + (lists before it); returns the offset behind the last list.
-// NB: blocks of 64 rows that can hold rows (16; 4 when S <= 256, where only gid.x / wv.x are looked at).
-template <int NB>
-__device__ __forceinline__ u32 fast_emit_ids_cols(const uint4& gid, u32 k, uint8_t* text, const u32 (&tokc)[16],
-                                                  const uint4& wv, u32 lane, u32 run0)
-{
-    const u32 tbase = (u32)(uintptr_t)text;   // LDS byte address (low half of the flat address)
-    u32 ex[15];                    // exclusive packed prefix of the row inside its block (8-bit fields)
-    u32 tot[15];                   // packed block totals (wave-uniform)
-    u32 ex15[2], tot15[2];
-    // byte totals, 16-bit fields: A[0] = groups 0 (low half) and 2, A[1] = groups 1 and 3
-    u32 A[2] = {0, 0};
-#define EDSX_A(I)                                                                                 \
-    if constexpr (I < NB) {                                                                       \
-        const u32 gi = byte_at<I>(gid);                                                           \
-        const u32 f = byte_at<I>(wv) << ((gi << 3) & 31u);                                        \
-        const u32 inc = wave_scan_incl(f);                                                        \
-        ex[I] = inc - f;                                                                          \
-        const u32 t = (u32)__builtin_amdgcn_readlane((int)inc, 63);                               \
-        tot[I] = t;                                                                               \
-        const u32 lo = t & 0x00ff00ffu, hi = (t >> 8) & 0x00ff00ffu;                              \
-        A[0] += (I >= 2) ? lo << 2 : lo;                                                          \
-        A[1] += (I >= 2) ? hi << 2 : hi;                                                          \
-    }
-    EDSX_A(0) EDSX_A(1) EDSX_A(2) EDSX_A(3) EDSX_A(4) EDSX_A(5) EDSX_A(6) EDSX_A(7)
-    EDSX_A(8) EDSX_A(9) EDSX_A(10) EDSX_A(11) EDSX_A(12) EDSX_A(13) EDSX_A(14)
-#undef EDSX_A
-    ex15[0] = ex15[1] = tot15[0] = tot15[1] = 0;
-    if constexpr (NB == 16) {
-        const u32 gi = byte_at<15>(gid);
-        const u32 f = byte_at<15>(wv) << (((gi >> 1) & 1u) * 16u);
+        u32 c[16];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const u32 fj = (gi & 1u) == (u32)j ? f : 0u;
-            const u32 inc = wave_scan_incl(fj);
-            ex15[j] = inc - fj;
-            tot15[j] = (u32)__builtin_amdgcn_readlane((int)inc, 63);
-            A[j] += tot15[j];
+        for (int g = 0; g < 16; g++) c[g] = L.tab[g * 64 + lane];
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            bbt[h] = 0; pre[2 * h] = 0; pre[2 * h + 1] = 0;
+            if ((u32)h * 2u < k) {
+                const u32 pk = c[2 * h] | (c[2 * h + 1] << 16);
+                const u32 sc = wave_scan_incl(pk), ex = sc - pk;
+                pre[2 * h] = ex & 0xffffu; pre[2 * h + 1] = ex >> 16;
+                bbt[h] = (u32)__builtin_amdgcn_readlane((int)sc, 63);
+            }
         }
     }
-    // group starts, and the packed cursors (same field layout as A)
-    u32 C[2] = {0, 0};
-    u32 run = run0, gstart[4], gend[4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        gstart[g] = run;
-        if ((u32)g < k) {
-            const int j = g & 1, sh = 16 * (g >> 1);
-            C[j] |= (run + 1) << sh;
-            run += 1 + ((A[j] >> sh) & 0xffffu);
+    // ---- geometry of string `lane` (lanes < k): bytes of its ids up to 128 / from 129, region in `stage`, offset in the output
+    u32 hb = 0, bb = 0;
+    if (lane < k) {
+        u32 t0 = tot0[0], t1 = tot1[0];
+        if (BITS == 4) {
+            const u32 q = lane >> 2;
+            t0 = q == 0 ? tot0[0] : q == 1 ? tot0[NQ > 1 ? 1 : 0] : q == 2 ? tot0[NQ > 2 ? 2 : 0] : tot0[NQ > 3 ? 3 : 0];
+            t1 = q == 0 ? tot1[0] : q == 1 ? tot1[NQ > 1 ? 1 : 0] : q == 2 ? tot1[NQ > 2 ? 2 : 0] : tot1[NQ > 3 ? 3 : 0];
         }
-        gend[g] = run;
+        hb = ((t0 >> ((lane & 3u) * 8u)) & 0xffu) + ((t1 >> ((lane & 3u) * 8u)) & 0xffu);
+        u32 tt = bbt[0];
+#pragma unroll
+        for (int h = 1; h < (BITS == 2 ? 2 : 8); h++) tt = (lane >> 1) == (u32)h ? bbt[h] : tt;
+        bb = (tt >> ((lane & 1u) * 16u)) & 0xffffu;
     }
-#define EDSX_CUR(gi) ((((gi & 1u) ? C[1] : C[0]) >> (((gi >> 1) & 1u) * 16u)) & 0xffffu)
-#define EDSX_B(I)                                                                                 \
-    if constexpr (I < NB) {                                                                       \
-        const u32 gi = byte_at<I>(gid);                                                           \
-        const u32 rank = (ex[I] >> ((gi << 3) & 31u)) & 0xffu;                                    \
-        const u32 off = EDSX_CUR(gi) + ((I >= 2) ? rank << 2 : rank);                             \
-        if (byte_at<I>(wv)) {                                                                     \
-            const u32 a = tbase + off, t = tokc[I];                                               \
-            if (I >= 2) lds_put4(a, t);                                                           \
-            else if (I == 0) { lds_put2(a, t); if (lane >= 9u) lds_put1<2>(a, t >> 16); }         \
-            else { lds_put2(a, t); lds_put1<2>(a, t >> 16); if (lane >= 35u) lds_put1<3>(a, t >> 24); } \
-        }                                                                                         \
-        const u32 lo = tot[I] & 0x00ff00ffu, hi = (tot[I] >> 8) & 0x00ff00ffu;                    \
-        C[0] += (I >= 2) ? lo << 2 : lo;                                                          \
-        C[1] += (I >= 2) ? hi << 2 : hi;                                                          \
+    const u32 sz = lane < k ? 1u + hb + bb : 0u;                 // '{' + tokens; the last ',' becomes '}'
+    const u32 rs = lane < k ? (sz + 6u) & ~3u : 0u;              // region: up to 3 bytes of padding in front
+    const u32 pk = rs | (sz << 16);
+    const u32 sc = wave_scan_incl(pk), exq = sc - pk;
+    const u32 total = (u32)__builtin_amdgcn_readlane((int)sc, 63) >> 16;
+    const u32 P = (exq & 0xffffu) + ((3u - hb) & 3u);            // (P + 1 + hb) % 4 == 0: the 4-byte tokens are aligned
+    const u32 off = exq >> 16;
+    if (lane < k) { L.gt[lane] = P + 1u; L.gt[16 + lane] = P + 1u + hb; }
+    // ---- cursors of this lane (rows 128..)
+#pragma unroll
+    for (int g = 0; g < (int)K; g++) L.tab[g * 64 + lane] = L.gt[16 + g] + pre[g];
+    // ---- tokens of rows 0..127
+    if (!(dbg & 4u)) {
+    if (v0) {
+        const u32 a = sbase + L.gt[g0] + ex0;
+        lds_put2(a, htok0);
+        if (lane >= 9u) lds_put1<2>(a, htok0 >> 16);
     }
-    EDSX_B(0) EDSX_B(1) EDSX_B(2) EDSX_B(3) EDSX_B(4) EDSX_B(5) EDSX_B(6) EDSX_B(7)
-    EDSX_B(8) EDSX_B(9) EDSX_B(10) EDSX_B(11) EDSX_B(12) EDSX_B(13) EDSX_B(14)
-#undef EDSX_B
-    if constexpr (NB == 16) {
-        const u32 gi = byte_at<15>(gid);
-        const u32 pk = (gi & 1u) ? ex15[1] : ex15[0];
-        const u32 off = EDSX_CUR(gi) + ((pk >> (((gi >> 1) & 1u) * 16u)) & 0xffffu);
-        if (byte_at<15>(wv)) {
-            const u32 a = tbase + off;
-            lds_put4(a, tokc[15]);
-            if (lane >= 39u) lds_put1<4>(a, (u32)',');
+    if (v1) {
+        u32 t0 = tot0[0];
+        if (BITS == 4) {
+            const u32 q = g1 >> 2;
+            t0 = q == 0 ? tot0[0] : q == 1 ? tot0[NQ > 1 ? 1 : 0] : q == 2 ? tot0[NQ > 2 ? 2 : 0] : tot0[NQ > 3 ? 3 : 0];
+        }
+        const u32 a = sbase + L.gt[g1] + ((t0 >> ((g1 & 3u) * 8u)) & 0xffu) + ex1;
+        lds_put2(a, htok1);
+        lds_put1<2>(a, htok1 >> 16);
+        if (lane >= 35u) lds_put1<3>(a, htok1 >> 24);
+    }
+    }
+    // ---- tokens of rows 128..
+    u32 at[16];
+    if (!(dbg & 2u)) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const bool act = (am & (1u << j)) != 0;
+        const u32 g = BITS == 2 ? (x0 >> (2u * j)) & 3u : ((j < 8 ? x0 : x1) >> (4u * (j & 7))) & 15u;
+        const u32 inc = act ? ((m5 >> j) & 1u ? 5u : 4u) : 0u;
+        at[j] = atomicAdd(&L.tab[(act ? g : K) * 64u + lane], inc);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        *reinterpret_cast<u32*>(L.stage + at[j]) = tokc[j];
+        // a fifth byte: only rows 999.. have one (wave-uniform test: does any lane have such a row j?)
+        if (HAS5 && ((j >= 7 && S > 992u + j) || S > 1008u + j)) {
+            const bool five = ((am & m5) >> j) & 1u;
+            L.stage[five ? at[j] + 4u : (u32)EM_STAGE + 4u * lane] = ',';
         }
     }
-#undef EDSX_CUR
-    if (lane == 0) {                               // braces last: the closing one replaces the final ','
-#pragma unroll
-        for (int g = 0; g < 4; g++) if ((u32)g < k) { text[gstart[g]] = '{'; text[gend[g] - 1] = '}'; }
     }
-    return run;
+    asm volatile("" ::: "memory");
+    // ---- braces (after the tokens: the closing one replaces the last ',')
+    if (lane < k) { L.stage[P] = '{'; L.stage[P + sz - 1u] = '}'; }
+    asm volatile("" ::: "memory");
+    // ---- copy the regions out.  String g: LDS [P, P + sz) -> gseds + off.  hn bytes up to the first 16-byte
+    // boundary of the LDS image, nfull aligned 16-byte chunks, tn bytes behind them.
+    pre_flush();                                                 // (the caller's wait for its prefetched loads)
+    const u32 lead = P & 15u;
+    const u32 hn = lead ? (sz < 16u - lead ? sz : 16u - lead) : 0u;
+    const u32 nfull = (sz - hn) >> 4;
+    const u32 cinc = wave_scan_incl(nfull), cs = cinc - nfull;
+    const u32 T = (u32)__builtin_amdgcn_readlane((int)cinc, 63);
+    if (lane < k) { L.gt[32 + lane] = P + hn - 16u * cs; L.gt[48 + lane] = off + hn - 16u * cs; }
+    if (!(dbg & 1u))
+    for (u32 t = lane; t < T; t += 64u) {
+        u32 g = 0;
+        for (u32 gg = 1; gg < k; gg++) g += t >= (u32)__builtin_amdgcn_readlane((int)cs, (int)gg) ? 1u : 0u;
+        const u32 src = L.gt[32 + g] + 16u * t, dst = L.gt[48 + g] + 16u * t;
+        store16u(gseds + dst, *reinterpret_cast<const uint4*>(L.stage + src));
+    }
+    const u32 pq = P | (sz << 16), oq = off | (hn << 16);
+    if (!(dbg & 1u))
+    for (u32 g = 0; g < k; g++) {
+        const u32 a = (u32)__builtin_amdgcn_readlane((int)pq, (int)g), b = (u32)__builtin_amdgcn_readlane((int)oq, (int)g);
+        const u32 Pg = a & 0xffffu, szg = a >> 16, og = b & 0xffffu, hg = b >> 16;
+        const u32 tail0 = hg + (((szg - hg) >> 4) << 4), tg = (szg - hg) & 15u;
+        if (lane < hg) gseds[og + lane] = L.stage[Pg + lane];
+        else if (lane >= 16u && lane - 16u < tg) gseds[og + tail0 + lane - 16u] = L.stage[Pg + tail0 + lane - 16u];
+    }
+    asm volatile("" ::: "memory");
+    return total;
 }
 
-// More than four groups (k <= 16): four at a time.  The group ids outside the current quartet get
-// weight 0 (SWAR: a byte is inside iff (id ^ base) & 0xFC == 0), the ids inside become 0..3.
-template <int NB>
-__device__ __forceinline__ u32 fast_emit_ids_cols_multi(const uint4& gid, u32 k, uint8_t* text, const u32 (&tokc)[16],
-                                                        const uint4& wv, u32 lane)
-{
-    u32 run = 0;
-    for (u32 gb = 0; gb < k; gb += 4) {
-        const u32 bb = gb * 0x01010101u;
-        uint4 g2, w2;
-#define EDSX_Q(C)                                                                                 \
-        { const u32 x = gid.C ^ bb; g2.C = x & 0x03030303u; w2.C = wv.C & ~bytes_ne_mask(x & 0xfcfcfcfcu, 0u); }
-        EDSX_Q(x) EDSX_Q(y) EDSX_Q(z) EDSX_Q(w)
-#undef EDSX_Q
-        run = fast_emit_ids_cols<NB>(g2, k - gb < 4u ? k - gb : 4u, text, tokc, w2, lane, run);
-    }
-    return run;
-}
+// what the emitter needs of a segment's record, requested one segment ahead
+struct EmitRec { uint4 x; u32 hv, rep, tb; u64 cm; };
 
-template <int NB>
-__global__ void __launch_bounds__(256, 4) k_emit_variant_fast(FastParams p)
+// WIDE false: the segments of up to four strings (2-bit group ids); true: those of 5..64 strings
+template <bool HAS5, bool WIDE>
+__global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
 {
-    __shared__ __attribute__((aligned(16))) u64 tok_sh[1024];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_sh[4][FAST_STAGE];
+    using WaveLds = EmitWaveLdsT<WIDE ? 17 : 5>;
+    __shared__ WaveLds lds_all[4];
     const MsaView& mv = p.mv;
     if (mv.hdr->status) return;
     const u32 lane = threadIdx.x & 63, wv = uniform32(threadIdx.x >> 6);
-    for (u32 r = threadIdx.x; r < 1024; r += 256) {
-        u32 id = r + 1, nd = ndigits(id);
-        u64 t = 0;
-        u32 v = id;
-        for (int i = (int)nd - 1; i >= 0; i--) { t |= (u64)('0' + v % 10u) << (8 * i); v /= 10u; }
-        t |= (u64)',' << (8 * nd);
-        tok_sh[r] = t | ((u64)(nd + 1) << 56);
-    }
-    __syncthreads();
-    uint8_t* stage = stage_sh[wv];
-    // lane constants of the packed-scan emitter: tokens and weights of rows lane, lane+64, ...
+    WaveLds& L = lds_all[wv];
+    const u32 S = mv.S;
+    L.tab[(WIDE ? 16 : 4) * 64 + lane] = (u32)EM_STAGE + 4u * lane;     // dummy cursors (never advanced: they are added 0)
+    // lane constants: tokens "ddd," of this lane's rows 16*lane .. +15 (ids 100..999; "dddd" from 1000), of rows
+    // `lane` and `64 + lane`, and which of this lane's rows are placed by the owning lane (rows >= 128)
     u32 tokc[16];
-    uint4 wgt;
-    {
-        uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const u32 r = (u32)i * 64u + lane;
-            tokc[i] = (u32)tok_sh[r];
-            const u32 tl = (u32)(tok_sh[r] >> 56);
-            if (r < mv.S) w[i >> 2] |= ((i < 2 || i == 15) ? tl : 1u) << ((i & 3) * 8);
-        }
-        wgt = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int j = 0; j < 16; j++) {
+        const u32 id = lane * 16u + j + 1u;
+        u32 t;
+        if (id >= 1000u) t = ('0' + id / 1000u) | (('0' + (id / 100u) % 10u) << 8) | (('0' + (id / 10u) % 10u) << 16) | (('0' + id % 10u) << 24);
+        else t = ('0' + id / 100u) | (('0' + (id / 10u) % 10u) << 8) | (('0' + id % 10u) << 16) | ((u32)',' << 24);
+        tokc[j] = t;
     }
+    u32 htok0, htok1;
+    {
+        const u32 a = lane + 1u, b = lane + 65u;
+        htok0 = a < 10u ? ('0' + a) | ((u32)',' << 8) : ('0' + a / 10u) | (('0' + a % 10u) << 8) | ((u32)',' << 16);
+        htok1 = b < 100u ? ('0' + b / 10u) | (('0' + b % 10u) << 8) | ((u32)',' << 16)
+                         : ('0' + b / 100u) | (('0' + (b / 10u) % 10u) << 8) | (('0' + b % 10u) << 16) | ((u32)',' << 24);
+    }
+    const u32 nvb = lane >= 8u && S > lane * 16u ? (S - lane * 16u < 16u ? S - lane * 16u : 16u) : 0u;
+    const u32 amv = (1u << nvb) - 1u;                       // rows >= 128 of this lane that exist
+    const bool hv0 = lane < S, hv1 = lane + 64u < S;
+    const u32 nl = (S + 15u) >> 4;
     const u64 nseg = *p.nseg_ptr;
-    const u64 p0 = mv.vbit(0) ? 0 : 1;
+    const u64 p0 = mv.vbit(0) ? 0 : 1;                      // variant and common segments alternate
     const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
     const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
-    const uint4 vmask = fast_valid_mask(lane, mv.S);
-    struct Rec { uint4 gid; u32 rep, chr, k; };
-    auto load_rec = [&](u64 v) -> Rec {
-        Rec r;
-        const uint8_t* rec = p.grec + v * (u64)GREC_BYTES;
-        r.gid = *reinterpret_cast<const uint4*>(rec + lane * 16u);
-        r.rep = *reinterpret_cast<const uint16_t*>(rec + GREC_REP + lane * 2u);
-        r.chr = rec[GREC_CHR + lane];
-        r.k = rec[GREC_K];
+    auto load_rec = [&](u64 meta) -> EmitRec {
+        EmitRec r;
+        r.x = make_uint4(0, 0, 0, 0); r.hv = 0; r.rep = 0; r.tb = 0; r.cm = 0;
+        if ((meta & META_REC) && ((meta & (META_KIND4 | META_KIND8)) != 0) == WIDE) {
+            const uint8_t* rec = p.rec + (meta & META_RECID) * (u64)p.rec_stride;
+            if (lane < nl) {
+                if (meta & META_KIND8) r.x = *reinterpret_cast<const uint4*>(rec + lane * 16u);
+                else if (meta & META_KIND4) { const uint2 v = *reinterpret_cast<const uint2*>(rec + lane * 8u); r.x.x = v.x; r.x.y = v.y; }
+                else r.x.x = *reinterpret_cast<const u32*>(rec + lane * 4u);
+            }
+            const uint8_t* hdr = rec + p.rec_gid;
+            r.hv = *reinterpret_cast<const u32*>(hdr);
+            if (meta & META_INLINE) r.tb = hdr[REC_H_TEXT + lane];
+            else {
+                r.cm = *reinterpret_cast<const u64*>(hdr + REC_H_SLOT);
+                r.rep = *reinterpret_cast<const uint16_t*>(hdr + REC_H_REP + lane * 2u);
+            }
+        }
         return r;
     };
-    // Software pipeline over the wave's segments t, t+nw, t+2nw ...: vmcnt retires in issue order, so a
-    // wait for a prefetched record also waits for every store issued before it.  The record of
-    // segment t+2 is therefore requested first, the id text of segment t is built in LDS (no
-    // global traffic), and only then the wave waits — by now the stores of segment t-1 have had the
-    // whole build phase to retire — and issues the stores of segment t.
-    u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + uniform32(threadIdx.x >> 6);
-    const u64 v0 = vi < nvs ? vi : 0, v1 = vi + nw < nvs ? vi + nw : v0;
-    Rec rc = load_rec(v0), rc_n = load_rec(v1);
-    u64 meta = uniform64(p.segmeta[2 * v0 + p0]), meta_n = uniform64(p.segmeta[2 * v1 + p0]);
-    u64 goff = uniform64(p.seds_len[2 * v0 + p0]), goff_n = uniform64(p.seds_len[2 * v1 + p0]);   // offsets after the scans
-    u64 eoff = uniform64(p.eds_len[2 * v0 + p0]), eoff_n = uniform64(p.eds_len[2 * v1 + p0]);
-    // nothing may be pending at the loop header, or the wait for it is placed inside the loop
-    asm volatile("" :: "v"(rc.gid.x), "v"(rc.gid.y), "v"(rc.gid.z), "v"(rc.gid.w), "v"(rc.rep), "v"(rc.chr), "v"(rc.k),
-                       "v"(rc_n.gid.x), "v"(rc_n.gid.y), "v"(rc_n.gid.z), "v"(rc_n.gid.w), "v"(rc_n.rep), "v"(rc_n.chr), "v"(rc_n.k));
+    // Software pipeline over the wave's segments vi, vi+nw, ...: vmcnt retires in issue order, so a wait for a
+    // prefetched record also waits for every store issued before it.  The record of the next segment (and the
+    // descriptor of the one after it) is therefore requested first, the id text of this segment is built in LDS
+    // (no global traffic), and only then the wave waits for the prefetch and issues this segment's stores.
+    u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + wv;
+    const u64 v0i = vi < nvs ? vi : 0, v1i = vi + nw < nvs ? vi + nw : v0i;
+    u64 meta = nvs ? uniform64(p.segmeta[2 * v0i + p0]) : 0, meta_n = nvs ? uniform64(p.segmeta[2 * v1i + p0]) : 0;
+    u64 qoff = nvs ? uniform64(p.seds_len[2 * v0i + p0]) : 0, qoff_n = nvs ? uniform64(p.seds_len[2 * v1i + p0]) : 0;
+    u64 eoff = nvs ? uniform64(p.eds_len[2 * v0i + p0]) : 0, eoff_n = nvs ? uniform64(p.eds_len[2 * v1i + p0]) : 0;
+    EmitRec rc = load_rec(meta);
     while (vi < nvs) {
         const u64 seg = 2 * vi + p0;
         const u64 v2 = vi + 2 * nw < nvs ? vi + 2 * nw : vi;
-        const Rec rc_nn = load_rec(v2);
+        const EmitRec rc_n = load_rec(vi + nw < nvs ? meta_n : 0);
         const u64 meta_v = p.segmeta[2 * v2 + p0];          // same address in every lane; made scalar
-        const u64 goff_v = p.seds_len[2 * v2 + p0];         // only after the wait below
+        const u64 qoff_v = p.seds_len[2 * v2 + p0];         // only after the wait below
         const u64 eoff_v = p.eds_len[2 * v2 + p0];
-        FastGroups G;
-        G.gid = rc.gid; G.k = uniform32(rc.k); G.rep = rc.rep; G.key_lo = rc.chr; G.key_hi = 0; G.sumlen = 0; G.len = 0;
-        const bool fast = G.k != 0;
-        u32 n = 0;
-        const u32 sh = (u32)goff & 15u;
-        if (fast) {
-            uint8_t* text = stage + sh;                    // LDS offset == global offset (mod 16)
-            if (G.k <= 4) n = fast_emit_ids_cols<NB>(G.gid, G.k, text, tokc, wgt, lane, 0u);
-            else if (G.k <= 16) n = fast_emit_ids_cols_multi<NB>(G.gid, G.k, text, tokc, wgt, lane);
-            else n = fast_emit_ids<0>(G.gid, G.k, text, tok_sh, lane);
-        }
-        // the wait for the prefetched record (and with it for the previous segment's stores) goes here
-        asm volatile("" :: "v"(rc_nn.gid.x), "v"(rc_nn.gid.y), "v"(rc_nn.gid.z), "v"(rc_nn.gid.w),
-                           "v"(rc_nn.rep), "v"(rc_nn.chr), "v"(rc_nn.k), "v"(meta_v), "v"(goff_v), "v"(eoff_v));
-        const u64 meta_nn = uniform64(meta_v), goff_nn = uniform64(goff_v), eoff_nn = uniform64(eoff_v);
-        if (fast) {
+        const bool fast = (meta & META_REC) != 0 && ((meta & (META_KIND4 | META_KIND8)) != 0) == WIDE;
+        const u32 hdr0 = uniform32(rc.hv);
+        const u32 k = hdr0 & 0xffu, textlen = (hdr0 >> 8) & 0xffu, ncol = (hdr0 >> 16) & 0xffu;
+        uint8_t* gseds = p.seds + qoff;
+        // the wait for the prefetched record: called right before this segment's id lists are stored (everything
+        // before that point that reads global memory is older than the prefetch or was waited for already)
+        auto pre_flush = [&]() {
+            asm volatile("" :: "v"(rc_n.x.x), "v"(rc_n.x.y), "v"(rc_n.x.z), "v"(rc_n.x.w), "v"(rc_n.hv), "v"(rc_n.rep),
+                               "v"(rc_n.tb), "v"(rc_n.cm), "v"(meta_v), "v"(qoff_v), "v"(eoff_v));
+        };
+        if (fast && !(p.dbg & 16u)) {
             // ---- eds: "{" s0 "," s1 ... "}"
-            {
-                uint8_t* e = p.eds + eoff;
-                const u32 ncol = (u32)(meta >> 48) & 0xffu;
-                if (ncol == 1) {                          // lane g holds group g's letter (0 = empty string)
-                    const u32 c = lane < G.k ? (u32)G.key_lo : 0u;
-                    const u64 nz = ballot64(c != 0);
-                    const u32 at = 1 + lane + mbcnt(nz);  // '{' + one separator per earlier group + earlier letters
-                    if (lane == 0) e[0] = '{';
-                    if (lane < G.k) {
-                        if (c) e[at] = (uint8_t)c;
-                        e[at + (c ? 1 : 0)] = (lane + 1 < G.k) ? ',' : '}';
-                    }
-                } else if (G.k * ncol <= 64u) {           // lane = (group, column): one load round trip
+            uint8_t* e = p.eds + eoff;
+            if (p.dbg & 8u) {
+            } else if (meta & META_INLINE) {
+                if (lane < textlen) e[lane] = (uint8_t)rc.tb;
+            } else {
+                const u64 cm = uniform64(rc.cm);
+                const u64 slot0 = cm & CNT_SLOT;
+                const bool scatter = (cm & CNT_SCATTER) != 0;
+                const u64 seg_a = scatter ? uniform64(p.seg_start[seg]) : 0;
+                const u32 rep_l = lane < k ? rc.rep : 0u;
+                if (k * ncol <= 64u) {                         // lane = (string, column): one load round trip
                     const u32 g = lane / ncol, c = lane - g * ncol;
-                    const u32 r = (u32)__shfl((int)G.rep, (int)(g < G.k ? g : 0u), 64);
+                    const u32 r = (u32)__shfl((int)rep_l, (int)(g < k ? g : 0u), 64);
                     u32 ch = 0;
-                    if (g < G.k) {
-                        const u64 sl = (meta & META_SCATTER) ? mv.slot(p.seg_start[seg] + c) : (meta & META_SLOT) + c;
-                        ch = mv.vc[sl * (u64)mv.Spad + vc_pos(r, mv.Gp)];
+                    if (g < k) {
+                        const u64 sl = scatter ? mv.slot(seg_a + c) : slot0 + c;
+                        ch = mv.vc[sl * (u64)mv.Spad + r];
                         if (ch == '-' || ch == '\n') ch = 0;
                     }
                     const u64 m = ballot64(ch != 0);
                     if (lane == 0) e[0] = '{';
                     if (ch) e[1 + g + mbcnt(m)] = (uint8_t)ch;
-                    if (g < G.k && c == 0) {              // separator after group g's letters
+                    if (g < k && c == 0) {                     // separator after string g's letters
                         const u32 endl = (g + 1) * ncol;
                         const u64 upto = endl >= 64u ? ~0ull : ((1ull << endl) - 1);
-                        e[1 + g + (u32)__builtin_popcountll(m & upto)] = (g + 1 < G.k) ? ',' : '}';
+                        e[1 + g + (u32)__builtin_popcountll(m & upto)] = (g + 1 < k) ? ',' : '}';
                     }
                 } else {
                     if (lane == 0) e[0] = '{';
                     u32 eo = 1;
-                    for (u32 g = 0; g < G.k; g++) {       // lane = column: the representative row's letters
-                        const u32 r = (u32)__builtin_amdgcn_readlane((int)G.rep, (int)g);
+                    for (u32 g = 0; g < k; g++) {              // lane = column: the first row's letters
+                        const u32 r = (u32)__builtin_amdgcn_readlane((int)rep_l, (int)g);
                         u32 ch = 0;
                         if (lane < ncol) {
-                            const u64 sl = (meta & META_SCATTER) ? mv.slot(p.seg_start[seg] + lane) : (meta & META_SLOT) + lane;
-                            ch = mv.vc[sl * (u64)mv.Spad + vc_pos(r, mv.Gp)];
+                            const u64 sl = scatter ? mv.slot(seg_a + lane) : slot0 + lane;
+                            ch = mv.vc[sl * (u64)mv.Spad + r];
                             if (ch == '-' || ch == '\n') ch = 0;
                         }
                         const u64 m = ballot64(ch != 0);
                         const u32 len = (u32)__builtin_popcountll(m);
                         if (ch) e[eo + mbcnt(m)] = (uint8_t)ch;
-                        if (lane == 0) e[eo + len] = (g + 1 < G.k) ? ',' : '}';
+                        if (lane == 0) e[eo + len] = (g + 1 < k) ? ',' : '}';
                         eo += len + 1;
                     }
                 }
             }
-            // ---- flush LDS -> HBM: aligned 16-byte blocks, byte stores for the ragged ends
-            uint8_t* gdst = p.seds + (goff - sh);          // 16-byte aligned image of `stage`
-            const u32 endo = sh + n;
-            const u32 body0 = sh ? 16u : 0u, body1 = endo & ~15u;
-            if (sh && lane < 16) { u32 o = lane; if (o >= sh && o < endo) gdst[o] = stage[o]; }
-            for (u32 o = body0 + lane * 16u; o + 16u <= body1; o += 1024u)
-                *reinterpret_cast<uint4*>(gdst + o) = *reinterpret_cast<const uint4*>(stage + o);
-            {
-                const u32 t0 = body1 > body0 ? body1 : body0;
-                if (lane < 16) { u32 o = t0 + lane; if (o < endo) gdst[o] = stage[o]; }
+            if (WIDE && (meta & META_KIND8)) {
+                // 17..64 strings: sixteen at a time (strings 16t .. 16t+15 of the rows whose id is in that range)
+                const u32 f = lane & 15u, src = lane >> 4;
+                auto head_gid = [&](u32 sl) -> u32 {        // (all four reads by all lanes: ds_bpermute takes data from active lanes only)
+                    const u32 dx = lane_read(rc.x.x, sl), dy = lane_read(rc.x.y, sl), dz = lane_read(rc.x.z, sl), dw = lane_read(rc.x.w, sl);
+                    const u32 d = (f >> 2) == 0 ? dx : (f >> 2) == 1 ? dy : (f >> 2) == 2 ? dz : dw;
+                    return (d >> ((f & 3u) * 8u)) & 0xffu;
+                };
+                const u32 G0 = head_gid(src), G1 = head_gid(src + 4u);
+                const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+                const uint2 xx = pack_gid4(rc.x, ones);
+                u32 run = 0;
+                for (u32 t = 0; t * 16u < k; t++) {
+                    const u32 tt = t * 0x01010101u;
+                    const u32 am = (eq_byte4((rc.x.x >> 4) & 0x0f0f0f0fu, tt) | (eq_byte4((rc.x.y >> 4) & 0x0f0f0f0fu, tt) << 4) |
+                                    (eq_byte4((rc.x.z >> 4) & 0x0f0f0f0fu, tt) << 8) | (eq_byte4((rc.x.w >> 4) & 0x0f0f0f0fu, tt) << 12)) & amv;
+                    const u32 kt = k - t * 16u < 16u ? k - t * 16u : 16u;
+                    run += emit_ids<WIDE ? 4 : 2, HAS5>(xx.x, xx.y, am, G0 & 15u, G1 & 15u, hv0 && (G0 >> 4) == t, hv1 && (G1 >> 4) == t,
+                                             kt, S, lane, tokc, htok0, htok1, L, gseds + run, pre_flush, p.dbg);
+                }
+            } else if (WIDE) {
+                const u32 f = lane & 15u, src = lane >> 4;
+                const u32 a0 = lane_read(rc.x.x, src), a1 = lane_read(rc.x.y, src), b0 = lane_read(rc.x.x, src + 4u), b1 = lane_read(rc.x.y, src + 4u);
+                const u32 g0 = (((f & 8u) ? a1 : a0) >> (4u * (f & 7u))) & 15u, g1 = (((f & 8u) ? b1 : b0) >> (4u * (f & 7u))) & 15u;
+                emit_ids<WIDE ? 4 : 2, HAS5>(rc.x.x, rc.x.y, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush, p.dbg);
+            } else {
+                const u32 f = lane & 15u, src = lane >> 4;
+                const u32 g0 = (lane_read(rc.x.x, src) >> (2u * f)) & 3u, g1 = (lane_read(rc.x.x, src + 4u) >> (2u * f)) & 3u;
+                emit_ids<WIDE ? 2 : 2, HAS5>(rc.x.x, 0u, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush, p.dbg);
             }
-        }
+        } else pre_flush();
         vi += nw;
-        rc = rc_n; meta = meta_n; goff = goff_n; eoff = eoff_n;
-        rc_n = rc_nn; meta_n = meta_nn; goff_n = goff_nn; eoff_n = eoff_nn;
+        rc = rc_n; meta = meta_n; qoff = qoff_n; eoff = eoff_n;
+        meta_n = uniform64(meta_v); qoff_n = uniform64(qoff_v); eoff_n = uniform64(eoff_v);
     }
 }
 
@@ -2183,11 +2180,11 @@ void MsaPipeline::plan_body(hipStream_t st)
     K1Params kp;
     kp.file = d_msa; kp.row_start = rows_.as<u64>(); kp.hdr = dh;
     kp.Vraw = vraw_.as<u64>(); kp.word_slot = wslot_.as<u64>(); kp.vc = vc_.as<uint8_t>();
-    kp.vc_cap_cols = vc_cap_cols_; kp.Draw = Draw; kp.lw = lw; kp.S = (u32)S; kp.Spad = Spad; kp.Gp = vc_rows_per_lane((u32)S);
+    kp.vc_cap_cols = vc_cap_cols_; kp.Draw = Draw; kp.lw = lw; kp.S = (u32)S; kp.Spad = Spad;
     kp.cpr_log2 = cpr_log2; kp.cap_cols = (u32)(colbuf_bytes / Spad); kp.ntiles = ntiles;
     if (kp.cap_cols == 0) throw FormatError(status_message(ST_TOO_MANY_ROWS));
     launch_timer_begin("k_scan_extract", st);
-    const bool lane_rows = hold && RPT == 16 && S <= 1024 && (u32)(T >> cpr_log2) == 4 * kp.Gp;   // thread rows = 16 consecutive vc bytes
+    const bool lane_rows = hold && RPT == 16;             // thread rows = 16 consecutive rows = 16 consecutive vc bytes
     if (cfg == 1) {
         if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
         else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
@@ -2237,7 +2234,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     // ---- K3 + K4: per-segment sizes, offsets
     mv_.file = d_msa; mv_.row_start = rows_.as<u64>(); mv_.V = V; mv_.Vraw = vraw_.as<u64>();
     mv_.word_slot = wslot_.as<u64>(); mv_.vc = vc_.as<uint8_t>(); mv_.hdr = dh; mv_.L = L; mv_.lw = lw;
-    mv_.S = (u32)S; mv_.Spad = Spad; mv_.Gp = vc_rows_per_lane((u32)S);
+    mv_.S = (u32)S; mv_.Spad = Spad;
     seg_start_p_ = seg_start; hseg_p_ = Hseg; segbase_p_ = segbase; nseg_p_ = d_nseg;
     seg_lds_ = (size_t)18 * S + 64 + (S <= HT_MAX_ROWS ? HtLds::BYTES + 16 : 0);
     seg_lds_ = (seg_lds_ + 15) & ~(size_t)15;
@@ -2262,26 +2259,24 @@ void MsaPipeline::plan_body(hipStream_t st)
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     if (fast_) {
         segmeta_.ensure(8 * (L + 2));
-        // list 1: too wide or mixed segments (k_seg_meta), list 2: those the fast kernel gives up on; together
+        // list 1: too wide or mixed segments (k_seg_meta), list 2: those the grouping kernel gives up on; together
         // at most all variant segments (<= L/2 + 1)
         slow_list_.ensure(8 * (L + 8));
+        cnt_list_.ensure(8 * (L / 2 + 4));                    // column descriptor per variant segment
         fp_.mv = mv_; fp_.seg_start = seg_start; fp_.nseg_ptr = d_nseg; fp_.segmeta = segmeta_.as<u64>();
         fp_.eds_len = eds_len_.as<u64>(); fp_.seds_len = seds_len_.as<u64>();
         fp_.slow_list = slow_list_.as<u64>(); fp_.slow_count = &dh->slow_n;
         fp_.slow_list2 = slow_list_.as<u64>() + (L / 2 + 4); fp_.slow_count2 = &dh->slow_n2;
+        fp_.cnt_meta = cnt_list_.as<u64>();
         fp_.eds = nullptr; fp_.seds = nullptr; fp_.tok_total = tok_total;
         // one record per variant segment; there are at most as many as variant columns
-        grec_.ensure(((size_t)vc_cap_cols_ + 2) * 1280);
-        fp_.grec = grec_.as<uint8_t>();
+        fp_.rec_stride = rec_stride((u32)S); fp_.rec_gid = rec_gid_bytes((u32)S);
+        rec_.ensure(((size_t)std::min<u64>(vc_cap_cols_, L / 2 + 2) + 2) * fp_.rec_stride);
+        fp_.rec = rec_.as<uint8_t>();
         EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, 2 * sizeof(u64), st));
         TIMED("k_seg_meta", st, hipLaunchKernelGGL(k_seg_meta, dim3(4096), dim3(256), 0, st, fp_));
-        if (S <= 256) {                                       // at most four rows per lane: leaner instantiation
-            TIMED("k_seg_count_fast", st, hipLaunchKernelGGL(k_seg_count_fast<4>, dim3(persistent_grid(
-                      reinterpret_cast<const void*>(k_seg_count_fast<4>), 256, 0)), dim3(256), 0, st, fp_));
-        } else {
-            TIMED("k_seg_count_fast", st, hipLaunchKernelGGL(k_seg_count_fast<16>, dim3(persistent_grid(
-                      reinterpret_cast<const void*>(k_seg_count_fast<16>), 256, 0)), dim3(256), 0, st, fp_));
-        }
+        TIMED("k_seg_group", st, hipLaunchKernelGGL(k_seg_group, dim3(persistent_grid(
+                  reinterpret_cast<const void*>(k_seg_group), 256, 0)), dim3(256), 0, st, fp_));
         sp.list = fp_.slow_list; sp.list_n = fp_.slow_count;
         TIMED("k_seg_count_slow", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
         sp.list = fp_.slow_list2; sp.list_n = fp_.slow_count2;
@@ -2405,12 +2400,17 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
         TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
         FastParams fp = fp_;
         fp.eds = d_eds; fp.seds = d_seds;
-        if (h_.S <= 256) {                                    // at most four blocks of 64 rows
-            TIMED("k_emit_variant_fast", st, hipLaunchKernelGGL(k_emit_variant_fast<4>, dim3(persistent_grid(
-                      reinterpret_cast<const void*>(k_emit_variant_fast<4>), 256, 0)), dim3(256), 0, st, fp));
+        { const char* e = getenv("EDSX_DBG"); fp.dbg = e ? (u32)atoi(e) : 0u; }
+        auto launch_emit = [&](auto kern, const char* name) {
+            TIMED(name, st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
+                                               dim3(256), 0, st, fp));
+        };
+        if (h_.S >= 1000) {                                   // ids of five bytes exist
+            launch_emit(k_emit_fast<true, false>, "k_emit_fast");
+            launch_emit(k_emit_fast<true, true>, "k_emit_fast_wide");
         } else {
-            TIMED("k_emit_variant_fast", st, hipLaunchKernelGGL(k_emit_variant_fast<16>, dim3(persistent_grid(
-                      reinterpret_cast<const void*>(k_emit_variant_fast<16>), 256, 0)), dim3(256), 0, st, fp));
+            launch_emit(k_emit_fast<false, false>, "k_emit_fast");
+            launch_emit(k_emit_fast<false, true>, "k_emit_fast_wide");
         }
         ep.list = fp_.slow_list; ep.list_n = fp_.slow_count;
         TIMED("k_emit_variant_slow", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));

@@ -83,34 +83,25 @@ struct MsaHdr {
     u64 slow_n2;       // ... and those the fast kernel gave up on (more than KCAP distinct strings)
     u64 idx_done;      // the speculative parallel row index validated: k_index_rows skips its chain
     u64 idx_bad;       // first row whose speculative header position did not validate
+    u64 cnt_n;         // variant segments handed to the wave-per-segment grouping kernel
+    u64 nrec;          // grouping records written by the column scan itself (fused segments)
 };
 
-// Row order inside one vc column.  Rows are dealt round-robin over the 64 lanes of a wave in
-// blocks of 1024 rows: row r sits at (r/1024)*1024 + (r%64)*Gp + (r%1024)/64, so ONE 16-byte load
-// at lane*Gp hands lane `lane` the rows lane, lane+64, lane+128, ...  (Gp = rows per lane = 16,
-// or ceil(S/64) when S <= 1024).  Consecutive row ids then sit in consecutive lanes, which makes
-// the id lists of the .seds a dense lane-parallel write.
-// rows per lane: a power of two (1, 2, 4, 8, 16), so that the 16 rows a K1 thread holds are 16
-// CONSECUTIVE bytes of a vc column for every S <= 1024 (see k_scan_extract, "lane rows")
-__host__ __device__ inline u32 vc_rows_per_lane(u32 S)
-{
-    if (S > 512) return 16u;
-    u32 g = 1;
-    while (64u * g < S) g <<= 1;
-    return g;
-}
-__host__ __device__ inline u32 vc_pitch(u32 S)
-{
-    const u32 gp = vc_rows_per_lane(S);
-    const u32 body = S > 1024 ? ((S + 1023u) / 1024u) * 1024u : 64u * gp;
-    return (body + 16u + 15u) / 16u * 16u;            // +16: the last lane may over-read 16 bytes
-}
-__host__ __device__ inline u32 vc_pos(u32 r, u32 gp) { return (r >> 10) * 1024u + (r & 63u) * gp + ((r & 1023u) >> 6); }
+// One vc column holds the bytes of one variant column in NATURAL row order: byte r = row r, pitch =
+// S rounded up to 16 plus 16 bytes of slack (a lane's 16-byte load at 16*lane never leaves the column).
+// The wave-per-segment kernels give lane l the rows 16l .. 16l+15 (one 16-byte load), so row order is
+// (lane, byte) and the ids of a lane's rows are consecutive numbers.
+__host__ __device__ inline u32 vc_pitch(u32 S) { return (S + 15u) / 16u * 16u + 16u; }
+
+// grouping record of a variant segment (wave-per-segment kernels, S <= 1024), see msa_device.hip
+constexpr u32 REC_HDR = 256;
+__host__ __device__ inline u32 rec_gid_bytes(u32 S) { return 16u * ((S + 15u) / 16u); }       // up to 8 bits per row
+__host__ __device__ inline u32 rec_stride(u32 S) { return (rec_gid_bytes(S) + REC_HDR + 63u) & ~63u; }
 
 // column access through V / vc (see msa_device.hip)
 struct MsaView {
     const uint8_t* file; const u64* row_start; const u64* V; const u64* Vraw; const u64* word_slot;
-    const uint8_t* vc; MsaHdr* hdr; u64 L, lw; u32 S, Spad, Gp;
+    const uint8_t* vc; MsaHdr* hdr; u64 L, lw; u32 S, Spad;
     __device__ __forceinline__ u64 raw(u64 c) const { return lw ? c + c / lw : c; }
     __device__ __forceinline__ u32 vbit(u64 c) const { return (u32)(V[c >> 6] >> (c & 63)) & 1u; }
     __device__ __forceinline__ u64 slot(u64 c) const
@@ -127,9 +118,11 @@ struct FastParams {
     MsaView mv; const u64* seg_start; const u64* nseg_ptr; u64* segmeta;
     u64* eds_len; u64* seds_len;            // sizes (count pass) == offsets (emit pass, after the scans)
     u64* slow_list; u64* slow_count;        // variant segments left to the generic kernels (k_seg_meta)
-    u64* slow_list2; u64* slow_count2;      // ... added by k_seg_count_fast
+    u64* slow_list2; u64* slow_count2;      // ... added by k_seg_group
+    u64* cnt_meta;                          // column descriptor per variant segment (0: generic kernels)
     uint8_t* eds; uint8_t* seds; u64 tok_total;
-    uint8_t* grec;                          // grouping records (count -> emit)
+    uint8_t* rec; u32 rec_stride, rec_gid;  // grouping records (count -> emit): stride, bytes of the group-id area
+    u32 dbg = 0;                            // EDSX_DBG: timing experiments (skips phases; output is then wrong)
 };
 
 class MsaPipeline {
@@ -171,7 +164,7 @@ private:
     std::vector<TimedKernel> timed_;
 
     DevBuf hdr_, rows_, vraw_, v_, wslot_, vc_, hrun_, hseg_, cnt_, wbase_, segbase_, scan_tmp_,
-           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, grec_, colbuf_, idx_tmp_;
+           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, cnt_list_, rec_, colbuf_, idx_tmp_;
     u64 vc_cap_cols_ = 0;
 
     // emit-time view
