@@ -278,7 +278,17 @@ struct K1Params {
     u64* Vraw; u64* word_slot; uint8_t* vc; u64 vc_cap_cols;
     u64 Draw, lw; u32 S, Spad, cpr_log2, cap_cols /* LDS colbuf capacity in columns */;
     u64 ntiles;
+    // fused grouping (context length 0, one-line rows, S <= 1024): the variant runs that lie inside a tile are
+    // grouped right here, from the LDS image of the tile's variant columns; only the other columns go to vc
+    u32 fuse; u64* Fraw; u32* rec_info; uint8_t* recf; u32 recf_stride, recf_gid;
+    u32 dbg;
 };
+constexpr u32 FUSE_MAXW = 10;      // widest run grouped by the column scan (exact 3-bit-per-column keys in one dword)
+constexpr u32 CLIST = 2048;        // variant columns per tile in fused mode (the LDS image holds at most 64 KB / 32 B columns)
+// fused record (indexed by the vc slot of the run's first column): group ids, 2 bits each (dword l = rows 16l..16l+15)
+// for up to 4 strings, 4 bits each (two dwords per lane) for 5..16; then at recf_gid: u32 k | textlen << 8, then the
+// .eds text "{s0,s1,..}" (<= REC_TEXT_MAX bytes).  rec_info[slot] = k | textlen << 8 | 4-bit ids << 30 | ok << 31
+constexpr u32 REC_TEXT_MAX = 64;
 
 __device__ __forceinline__ u32 chunk_ne16(const uint4& a, const uint4& b)
 {
@@ -298,6 +308,323 @@ template <int I> __device__ __forceinline__ u32 byte_at(const uint4& v)
     return (w >> ((I & 3) * 8)) & 0xffu;
 }
 
+// ---- grouping primitives of the wave-per-segment code (used by the column scan below for the segments it
+// groups itself, and by k_seg_group): one wave per variant segment, lane l owns rows 16l .. 16l+15
+constexpr int KCAP = 64;                  // distinct strings per fast segment (group g lives in lane g)
+__device__ __forceinline__ uint32_t bytes_ne_mask(uint32_t a, uint32_t b)   // 0xFF where bytes differ
+{
+    uint32_t x = a ^ b;
+    uint32_t h = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // 0x80 where the bytes differ
+    return h | (h - (h >> 7));              // -> 0xFF; (h >> 7) * 0xff would be a quarter-rate v_mul_lo_u32
+}
+__device__ __forceinline__ uint4 bytes_eq_mask(const uint4& a, uint32_t cccc)
+{
+    return make_uint4(~bytes_ne_mask(a.x, cccc), ~bytes_ne_mask(a.y, cccc), ~bytes_ne_mask(a.z, cccc),
+                      ~bytes_ne_mask(a.w, cccc));
+}
+__device__ __forceinline__ bool any4(const uint4& v) { return (v.x | v.y | v.z | v.w) != 0; }
+// does this lane hold a NUL byte in one of its existing rows?
+__device__ __forceinline__ bool any_nul(const uint4& c, const uint4& vmask)
+{
+    const uint4 z = bytes_eq_mask(c, 0u);
+    return ((z.x & vmask.x) | (z.y & vmask.y) | (z.z & vmask.z) | (z.w & vmask.w)) != 0;
+}
+__device__ __forceinline__ u32 first_byte_index(const uint4& m)   // m bytes are 0x00 / 0xFF
+{
+    return m.x ? (u32)__builtin_ctz(m.x) >> 3
+               : m.y ? 4u + ((u32)__builtin_ctz(m.y) >> 3)
+                     : m.z ? 8u + ((u32)__builtin_ctz(m.z) >> 3) : m.w ? 12u + ((u32)__builtin_ctz(m.w) >> 3) : 16u;
+}
+// byte `idx` (wave-uniform) of lane `leader`'s 16-byte vector, as a wave-uniform value
+__device__ __forceinline__ u32 leader_byte(const uint4& v, int leader, u32 idx)
+{
+    const u32 x = (u32)__builtin_amdgcn_readlane((int)v.x, leader), y = (u32)__builtin_amdgcn_readlane((int)v.y, leader);
+    const u32 z = (u32)__builtin_amdgcn_readlane((int)v.z, leader), w = (u32)__builtin_amdgcn_readlane((int)v.w, leader);
+    const u32 d = idx < 8 ? (idx < 4 ? x : y) : (idx < 12 ? z : w);
+    return (d >> ((idx & 3) * 8)) & 0xffu;
+}
+// '-' and '\n' contribute nothing to a row's string (msa_transforms.cpp:283): normalise to 0
+template <bool CHECK_NL>
+__device__ __forceinline__ uint4 normalise_col(const uint4& c, const uint4& vmask, u32& saw_nl)
+{
+    uint4 gap = bytes_eq_mask(c, 0x2d2d2d2du);
+    if (CHECK_NL) {
+        uint4 nl = bytes_eq_mask(c, 0x0a0a0a0au);
+        if (any4(make_uint4(nl.x & vmask.x, nl.y & vmask.y, nl.z & vmask.z, nl.w & vmask.w))) saw_nl = 1;
+        gap.x |= nl.x; gap.y |= nl.y; gap.z |= nl.z; gap.w |= nl.w;
+    }
+    return make_uint4(c.x & ~gap.x, c.y & ~gap.y, c.z & ~gap.z, c.w & ~gap.w);
+}
+
+struct FastGroups {
+    uint4 gid;            // byte i = group of row 16*lane+i (0xFF: no such row)
+    u32 k;                // number of distinct strings (wave-uniform)
+    u32 sumlen;           // sum of their lengths
+    // lane g holds the state of group g
+    u64 key_lo, key_hi;   // the group's gap-stripped string (packed) or its hash, + length
+    u32 rep;              // representative row (first row of the group in row order)
+    u32 len;              // length of the group's string
+};
+
+// lane-private validity mask: byte i = 0xFF iff row 16*lane+i exists
+__device__ __forceinline__ uint4 fast_valid_mask(u32 lane, u32 S)
+{
+    const u32 base = lane * 16u;
+    const u32 n = S > base ? (S - base < 16u ? S - base : 16u) : 0u;       // existing rows of this lane
+    auto word = [&](u32 o) -> uint32_t { return n >= o + 4u ? 0xffffffffu : (n > o ? (1u << (8u * (n - o))) - 1u : 0u); };
+    return make_uint4(word(0), word(4), word(8), word(12));
+}
+
+// assign the rows in `eq` to the group with key (klo,khi): an existing one or a new one.
+// Returns false when KCAP is exceeded.
+__device__ __forceinline__ bool fast_assign(FastGroups& G, uint4& rm, const uint4& eq, u64 klo, u64 khi,
+                                            u32 len, u32 lane, u32 rep_row)
+{
+    const u64 hit = ballot64(lane < G.k && G.key_lo == klo && G.key_hi == khi);
+    u32 gsel;
+    if (hit) gsel = (u32)__builtin_ctzll(hit);
+    else {
+        if (G.k >= (u32)KCAP) return false;
+        gsel = G.k;
+        if (lane == gsel) { G.key_lo = klo; G.key_hi = khi; G.rep = rep_row; G.len = len; }
+        G.k++;
+        G.sumlen += len;
+    }
+    const uint32_t gg = gsel * 0x01010101u;
+    G.gid.x = (G.gid.x & ~eq.x) | (eq.x & gg); G.gid.y = (G.gid.y & ~eq.y) | (eq.y & gg);
+    G.gid.z = (G.gid.z & ~eq.z) | (eq.z & gg); G.gid.w = (G.gid.w & ~eq.w) | (eq.w & gg);
+    rm.x &= ~eq.x; rm.y &= ~eq.y; rm.z &= ~eq.z; rm.w &= ~eq.w;
+    return true;
+}
+
+// signature weights of the multi-column grouping: W_j(c), 24 bit, odd.  A compile-time table (read
+// with scalar loads) instead of two v_mul_lo_u32 per weight.
+struct FastWeights {
+    u32 v[64 * 3];
+    constexpr FastWeights() : v{} {
+        for (u32 c = 0; c < 64; c++)
+            for (u32 j = 0; j < 3; j++) {
+                u32 x = (c + 1u) * 0x9e3779b1u + (j + 1u) * 0x85ebca77u;
+                x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+                v[c * 3 + j] = (x | 1u) & 0xffffffu;
+            }
+    }
+};
+__device__ const FastWeights FAST_W{};
+
+template <int CTRL, int ROWMASK> __device__ __forceinline__ u32 dpp_move0(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);   // lanes without a source get 0
+}
+// XOR / OR of v over the 64 lanes, wave-uniform (DPP row shifts and broadcasts; lane 63 ends up with all)
+__device__ __forceinline__ u32 wave_xor_all(u32 v)
+{
+    v ^= dpp_move0<0x111, 0xf>(v);       // row_shr:1
+    v ^= dpp_move0<0x112, 0xf>(v);       // row_shr:2
+    v ^= dpp_move0<0x114, 0xf>(v);       // row_shr:4
+    v ^= dpp_move0<0x118, 0xf>(v);       // row_shr:8   -> lane 15 of every row: the row's XOR
+    v ^= dpp_move0<0x142, 0xa>(v);       // row_bcast:15 -> rows 1, 3
+    v ^= dpp_move0<0x143, 0xc>(v);       // row_bcast:31 -> rows 2, 3
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ u32 wave_or_all(u32 v)
+{
+    v |= dpp_move0<0x111, 0xf>(v); v |= dpp_move0<0x112, 0xf>(v); v |= dpp_move0<0x114, 0xf>(v);
+    v |= dpp_move0<0x118, 0xf>(v); v |= dpp_move0<0x142, 0xa>(v); v |= dpp_move0<0x143, 0xc>(v);
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ u32 wave_scan_incl(u32 v)
+{
+    v += dpp_move0<0x111, 0xf>(v);       // row_shr:1
+    v += dpp_move0<0x112, 0xf>(v);       // row_shr:2
+    v += dpp_move0<0x114, 0xf>(v);       // row_shr:4
+    v += dpp_move0<0x118, 0xf>(v);       // row_shr:8
+    v += dpp_move0<0x142, 0xa>(v);       // row_bcast:15 -> rows 1, 3
+    v += dpp_move0<0x143, 0xc>(v);       // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// minimum of v over lanes 0..7 (wave-uniform)
+__device__ __forceinline__ u32 min_lanes8(u32 v)
+{
+    u32 t;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;
+    return (u32)__builtin_amdgcn_readlane((int)v, 7);
+}
+
+// class code of the DNA alphabet {A, C, G, T, N, -}: class(b) = ((b >> 1) ^ (b >> 2)) & 7 :
+//   A 0, C 1, G 2, N 4, '-' 5, T 7  (3 and 6 unused).  Any other byte (lower case, IUPAC codes, NUL, a stray
+// newline) fails the reverse lookup (v_perm_b32 = four lookups in an 8-entry table per instruction).
+constexpr u32 DNA_LET_LO = 0x00474341u, DNA_LET_HI = 0x54002d4eu;      // class -> letter (0: unused class)
+__device__ __forceinline__ uint4 dna_classes(const uint4& x)
+{
+    return make_uint4(((x.x >> 1) ^ (x.x >> 2)) & 0x07070707u, ((x.y >> 1) ^ (x.y >> 2)) & 0x07070707u,
+                      ((x.z >> 1) ^ (x.z >> 2)) & 0x07070707u, ((x.w >> 1) ^ (x.w >> 2)) & 0x07070707u);
+}
+__device__ __forceinline__ u32 dna_bad(const uint4& x, const uint4& cls, const uint4& vmask)
+{
+    return ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.x) ^ x.x) & vmask.x) |
+           ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.y) ^ x.y) & vmask.y) |
+           ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.z) ^ x.z) & vmask.z) |
+           ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.w) ^ x.w) & vmask.w);
+}
+
+// One column over {A, C, G, T, N, -}: the grouping of msa_transforms.cpp:262-293 with byte-table lookups.
+//   rb   = the column's byte of row `lane` (rows 0..63 one per lane: most classes first appear there, and then
+//          their first row is one ballot away)
+// Group ids are the ranks of the classes by first row (no loop over the groups: lane c ranks class c against the
+// other seven with readlanes); group g's state lands in lane g as in fast_assign.
+__device__ __forceinline__ bool fast_group_dna1(const uint4& x, u32 rb, const uint4& vmask, u32 lane, u32 S, FastGroups& G)
+{
+    constexpr u32 OH_LO = 0x08040201u, OH_HI = 0x80402010u;        // class -> 1 << class
+    uint4 cls = dna_classes(x);
+    if (ballot64(dna_bad(x, cls, vmask) != 0)) return false;
+    // classes present in this lane's rows, and in the column
+    u32 pl = (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.x) & vmask.x) | (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.y) & vmask.y) |
+             (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.z) & vmask.z) | (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.w) & vmask.w);
+    pl |= pl >> 16; pl |= pl >> 8; pl &= 0xffu;
+    const u32 P = wave_or_all(pl);
+    const u32 rc = lane < S ? (((rb >> 1) ^ (rb >> 2)) & 7u) : 8u;  // class of row `lane`
+    // first row of every class: lane c keeps class c's (classes that are absent: ~0)
+    u32 firstv = 0xffffffffu;
+    for (u32 mm = P; mm; mm &= mm - 1) {
+        const u32 c = (u32)__builtin_ctz(mm);
+        const u64 b = ballot64(rc == c);
+        u32 f;
+        if (b) f = (u32)__builtin_ctzll(b);
+        else {                                             // not among the first 64 rows
+            const int L = __builtin_ctzll(ballot64(((pl >> c) & 1u) != 0));
+            uint4 e = bytes_eq_mask(cls, c * 0x01010101u);
+            e.x &= vmask.x; e.y &= vmask.y; e.z &= vmask.z; e.w &= vmask.w;
+            f = 16u * (u32)L + (u32)__builtin_amdgcn_readlane((int)first_byte_index(e), L);
+        }
+        firstv = lane == c ? f : firstv;
+    }
+    // rank of class `lane` by first row = its group id (first rows are distinct)
+    u32 rank = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) rank += (u32)__builtin_amdgcn_readlane((int)firstv, c) < firstv ? 1u : 0u;
+    // table class -> group: byte c of (lut_hi:lut_lo); OR over lanes 0..3 / 4..7 (row_shr within the first DPP row)
+    u32 vlo = lane < 4u ? rank << (8u * lane) : 0u, vhi = (lane >= 4u && lane < 8u) ? rank << (8u * (lane - 4u)) : 0u;
+    vlo |= dpp_move0<0x111, 0xf>(vlo); vhi |= dpp_move0<0x111, 0xf>(vhi);
+    vlo |= dpp_move0<0x112, 0xf>(vlo); vhi |= dpp_move0<0x112, 0xf>(vhi);
+    vlo |= dpp_move0<0x114, 0xf>(vlo); vhi |= dpp_move0<0x114, 0xf>(vhi);
+    const u32 lut_lo = (u32)__builtin_amdgcn_readlane((int)vlo, 7), lut_hi = (u32)__builtin_amdgcn_readlane((int)vhi, 7);
+    cls.x |= ~vmask.x; cls.y |= ~vmask.y; cls.z |= ~vmask.z; cls.w |= ~vmask.w;   // rows that do not exist: 0xFF
+    G.gid = make_uint4(__builtin_amdgcn_perm(lut_hi, lut_lo, cls.x), __builtin_amdgcn_perm(lut_hi, lut_lo, cls.y),
+                       __builtin_amdgcn_perm(lut_hi, lut_lo, cls.z), __builtin_amdgcn_perm(lut_hi, lut_lo, cls.w));
+    // group g's letter, first row and length -> lane g
+    G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
+    for (u32 mm = P; mm; mm &= mm - 1) {
+        const u32 c = (u32)__builtin_ctz(mm);
+        const u32 r = (u32)__builtin_amdgcn_readlane((int)rank, (int)c), f = (u32)__builtin_amdgcn_readlane((int)firstv, (int)c);
+        const u32 letter = c == 5u ? 0u : (u32)((((u64)DNA_LET_HI << 32) | DNA_LET_LO) >> (8u * c)) & 0xffu;
+        if (lane == r) { G.key_lo = letter; G.rep = f; G.len = letter ? 1u : 0u; }
+    }
+    G.k = (u32)__builtin_popcount(P);
+    G.sumlen = (u32)__builtin_popcount(P & ~(1u << 5));
+    return true;
+}
+
+// the not yet grouped row that comes first in row order (lane, byte): its lane and byte index (uniform)
+__device__ __forceinline__ bool first_remaining(const uint4& rm, int& leader, u32& i0)
+{
+    const u64 b = ballot64(any4(rm));
+    if (!b) return false;
+    leader = __builtin_ctzll(b);
+    i0 = (u32)__builtin_amdgcn_readlane((int)first_byte_index(rm), leader);
+    return true;
+}
+
+// 2..20 columns over {A,C,G,T,N,-}: EXACT raw keys, 3 bits per column (class code), NK dwords of ten columns
+// per row.  Rows with equal keys are byte-identical; a raw group's gap-stripped string is read off its key
+// (drop the gap classes), so no row is re-read.  Returns 1 done, 0 another alphabet, -1 more than KCAP strings.
+template <int NK, class LoadCol>
+__device__ __forceinline__ int fast_group_dnakeys(LoadCol load_col, u32 ncol, const uint4& col0, u32 lane, const uint4& vmask,
+                                                  FastGroups& G)
+{
+    u32 key[NK][16];
+#pragma unroll
+    for (int n = 0; n < NK; n++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) key[n][i] = 0;
+    u32 badacc = 0;
+#define EDSX_K(I) key[n][I] |= byte_at<I>(cls) << sh;
+#pragma unroll
+    for (int n = 0; n < NK; n++) {
+        const u32 cbase = 10u * n, cend = ncol < cbase + 10u ? ncol : cbase + 10u;
+        for (u32 c0 = cbase; c0 < cend; c0 += 4) {
+            uint4 cvs[4];                              // four column loads in flight
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cvs[j] = make_uint4(0, 0, 0, 0);
+                if (c0 + j < cend) cvs[j] = (c0 + j == 0) ? col0 : load_col(c0 + j);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (c0 + j < cend) {
+                    const uint4 x = cvs[j];
+                    const uint4 cls = dna_classes(x);
+                    badacc |= dna_bad(x, cls, vmask);
+                    const u32 sh = 3u * (c0 + j - cbase);
+                    EDSX_K(0) EDSX_K(1) EDSX_K(2) EDSX_K(3) EDSX_K(4) EDSX_K(5) EDSX_K(6) EDSX_K(7)
+                    EDSX_K(8) EDSX_K(9) EDSX_K(10) EDSX_K(11) EDSX_K(12) EDSX_K(13) EDSX_K(14) EDSX_K(15)
+                }
+            }
+        }
+    }
+#undef EDSX_K
+    if (ballot64(badacc != 0)) return 0;
+    uint4 rm = vmask;
+    int leader;
+    u32 i0;
+    while (first_remaining(rm, leader, i0)) {
+        u32 rk[NK];
+#pragma unroll
+        for (int n = 0; n < NK; n++) {
+            u32 mk = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) mk = (i0 == (u32)i) ? key[n][i] : mk;
+            rk[n] = (u32)__builtin_amdgcn_readlane((int)mk, leader);
+        }
+        uint32_t e[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            bool same = key[0][i] == rk[0];
+            if (NK > 1) same = same && key[NK - 1][i] == rk[NK - 1];
+            if (same) e[i >> 2] |= 0xffu << ((i & 3) * 8);
+        }
+        const uint4 eq = make_uint4(e[0] & rm.x, e[1] & rm.y, e[2] & rm.z, e[3] & rm.w);
+        // the group's string: its key without the gap classes; lane = column
+        u32 cl = 5u;
+        if (lane < ncol) cl = ((lane < 10u ? rk[0] : rk[NK - 1]) >> (3u * (lane < 10u ? lane : lane - 10u))) & 7u;
+        const u64 nz = ballot64(cl != 5u);
+        const u32 len = (u32)__builtin_popcountll(nz), pos = mbcnt(nz);
+        u32 klo = 0, khi = 0;                              // 3 bits per letter, ten letters per dword
+        if (cl != 5u) { if (pos < 10u) klo = cl << (3u * pos); else khi = cl << (3u * (pos - 10u)); }
+        klo = wave_or_all(klo);
+        if (NK > 1) khi = wave_or_all(khi);
+        if (!fast_assign(G, rm, eq, ((u64)khi << 32) | klo, (u64)len << 32, len, lane, (u32)leader * 16u + i0)) return -1;
+    }
+    return 1;
+}
+
+
+// group-id bytes of this lane's 16 rows -> 2 bits per row (ids 0..3; rows that do not exist: 0)
+__device__ __forceinline__ u32 pack_gid2(const uint4& gid, const uint4& vmask)
+{
+    auto p = [](uint32_t x) -> u32 { x &= 0x03030303u; x |= x >> 6; x |= x >> 12; return x & 0xffu; };
+    return p(gid.x & vmask.x) | (p(gid.y & vmask.y) << 8) | (p(gid.z & vmask.z) << 16) | (p(gid.w & vmask.w) << 24);
+}
+// ... -> 4 bits per row (ids 0..15): rows 0..7 in .x, 8..15 in .y
+__device__ __forceinline__ uint2 pack_gid4(const uint4& gid, const uint4& vmask)
+{
+    auto p = [](uint32_t x) -> u32 { x &= 0x0f0f0f0fu; x |= x >> 4; return (x & 0xffu) | ((x >> 8) & 0xff00u); };
+    return make_uint2(p(gid.x & vmask.x) | (p(gid.y & vmask.y) << 16), p(gid.z & vmask.z) | (p(gid.w & vmask.w) << 16));
+}
+
 template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW>
 __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 {
@@ -306,6 +633,9 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     __shared__ u32 pre[256];
     __shared__ u32 wtot[4];
     __shared__ u64 slot_base_sh;
+    __shared__ u32 CS[256];            // fused: per chunk, first columns of the runs grouped here
+    __shared__ uint16_t clist[CLIST];  // fused: from the front those runs (colbuf index | width << 12), from the back the colbuf
+    __shared__ u32 ncand_sh, nst_sh;   //        indices of the variant columns that go to vc; their numbers
 
     const u32 tid = threadIdx.x;
     const u32 cpr = 1u << p.cpr_log2;
@@ -328,11 +658,15 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     const int nb = q < p.Draw ? ((p.Draw - q) < 16 ? (int)(p.Draw - q) : 16) : 0;
     const u32 valid = nb == 16 ? 0xffffu : ((1u << nb) - 1u);
 
+    if ((p.dbg & 1024u) && ((blockIdx.x >> 8) & 1u) && blockIdx.x < 512u) {        // experiment: the two workgroups of a CU out of phase
+        for (int i = 0; i < 3; i++) __builtin_amdgcn_s_sleep(127);
+    }
     // row starts -> LDS (the colbuf area is free until the extraction phase), so the data loads
     // below depend on fast ds_reads only and all RPT of them are in flight together
     u64* rs = reinterpret_cast<u64*>(colbuf);
     for (u32 r = tid; r < p.S; r += T) rs[r] = p.row_start[r];
-    if (tid < 256) D[tid] = 0;
+    if (tid < 256) { D[tid] = 0; CS[tid] = 0; }
+    if (tid == 0) { ncand_sh = 0; nst_sh = 0; }
     __syncthreads();
 
     const uint8_t* f = p.file;
@@ -441,6 +775,142 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
             EDSX_T(0, x) EDSX_T(1, y) EDSX_T(2, z) EDSX_T(3, w)
 #undef EDSX_T
         }
+        bool fused_tile = false;
+        if constexpr (HOLD && LANEROWS) fused_tile = p.fuse && nv && nv <= cap && nv <= CLIST && !(p.dbg & 128u);   // workgroup-uniform
+        if (fused_tile) { if constexpr (HOLD && LANEROWS) {
+            // ---- all variant columns of the tile -> LDS (column-major, natural row order)
+            if (V16) {
+                u32 idx = pre_of(j);
+#define EDSX_L(I)                                                                                 \
+                if (V16 & (1u << I)) {                                                            \
+                    if (sub * 16u < p.S)                                                          \
+                        *reinterpret_cast<uint4*>(colbuf + (size_t)idx * p.Spad + sub * 16) =     \
+                            make_uint4(tr[I][0], tr[I][1], tr[I][2], tr[I][3]);                    \
+                    idx++;                                                                        \
+                }
+                EDSX_L(0) EDSX_L(1) EDSX_L(2) EDSX_L(3) EDSX_L(4) EDSX_L(5) EDSX_L(6) EDSX_L(7)
+                EDSX_L(8) EDSX_L(9) EDSX_L(10) EDSX_L(11) EDSX_L(12) EDSX_L(13) EDSX_L(14) EDSX_L(15)
+#undef EDSX_L
+            }
+            // ---- the runs of variant columns that lie inside the tile and are at most FUSE_MAXW wide are grouped here
+            // (registered by the thread that owns their first column); every other variant column goes to vc
+            if (tid < cpr && !(p.dbg & 256u)) {
+                const u32 m = D[tid];
+                // window: previous, own and the next two chunks.  Beyond the tile the runs may go on: all ones there
+                const u64 w = (tid ? (u64)D[tid - 1] : 0xffffull) | ((u64)m << 16) | ((u64)(tid + 1 < cpr ? D[tid + 1] : 0xffffu) << 32) |
+                              ((u64)(tid + 2 < cpr ? D[tid + 2] : 0xffffu) << 48);
+                const u32 idxb = pre_of(tid);
+                u32 cs = 0;
+                for (u32 mm = m; mm; mm &= mm - 1) {
+                    const u32 b = (u32)__builtin_ctz(mm), pp = 16u + b;
+                    const u32 up = (u32)__builtin_ctzll(~(w >> pp));                 // ones from this column upwards
+                    const u32 dn = (u32)__builtin_clzll(~(w << (64u - pp)));         // ones below it
+                    const u32 idx = idxb + (u32)__builtin_popcount(m & ((1u << b) - 1u));
+                    // (a run that reaches the bottom of the window may be longer than it looks: not for this path.
+                    // Upwards the window shows at least 32 columns, so the thread of a run's first column sees it whole.)
+                    if (up + dn > FUSE_MAXW || dn == pp) clist[CLIST - 1u - atomicAdd(&nst_sh, 1u)] = (uint16_t)idx;
+                    else if (dn == 0) { clist[atomicAdd(&ncand_sh, 1u)] = (uint16_t)(idx | ((up + dn) << 11)); cs |= 1u << b; }
+                }
+                CS[tid] = cs;
+            }
+            if (tid == 0) {                                    // first use of the atomic's result
+                slot_base_sh = base_r;
+                if (base_r + nv > p.vc_cap_cols) atomicOr(&p.hdr->status, (u64)ST_VC_OVERFLOW);
+            }
+            __syncthreads();
+            slot_base = slot_base_sh;
+            overflow = slot_base + nv > p.vc_cap_cols;
+            if (tid < cpr / 4) {                               // V words, per-word slot base, first columns of the fused runs
+                u64 wi = q0 / 64 + tid;
+                if (wi * 64 < p.Draw) {
+                    p.Vraw[wi] = (u64)D[4 * tid] | ((u64)D[4 * tid + 1] << 16) | ((u64)D[4 * tid + 2] << 32) | ((u64)D[4 * tid + 3] << 48);
+                    p.word_slot[wi] = slot_base + pre_of(4 * tid);
+                    p.Fraw[wi] = (u64)CS[4 * tid] | ((u64)CS[4 * tid + 1] << 16) | ((u64)CS[4 * tid + 2] << 32) | ((u64)CS[4 * tid + 3] << 48);
+                }
+            }
+            if (!overflow) {
+                if (p.dbg & 2048u) {                           // experiment: copy everything as the unfused path does
+                    const size_t nbytes = (size_t)nv * p.Spad;
+                    uint8_t* g = p.vc + slot_base * (u64)p.Spad;
+                    for (size_t o = (size_t)tid * 16; o < nbytes; o += (size_t)T * 16)
+                        *reinterpret_cast<uint4*>(g + o) = *reinterpret_cast<const uint4*>(colbuf + o);
+                }
+                // ---- the other variant columns: LDS -> vc, one wave per column
+                {
+                    const u32 nst = (p.dbg & 512u) ? 0u : nst_sh, vec = p.Spad / 16u, ln = tid & 63u;
+                    for (u32 c = uniform32(tid >> 6); c < nst; c += T / 64) {
+                        const u32 idx = clist[CLIST - 1u - c];
+                        const uint8_t* src = colbuf + (size_t)idx * p.Spad;
+                        uint8_t* g = p.vc + (slot_base + idx) * (u64)p.Spad;
+                        for (u32 pc = ln; pc < vec; pc += 64u)
+                            *reinterpret_cast<uint4*>(g + pc * 16u) = *reinterpret_cast<const uint4*>(src + pc * 16u);
+                    }
+                }
+                // ---- group the runs: one wave per run, lane l = rows 16l .. 16l+15 (msa_transforms.cpp:262-293)
+                const u32 ncand = (p.dbg & 32u) ? 0u : ncand_sh;
+                const u32 lane = tid & 63u, nl = (p.S + 15u) >> 4;
+                const uint4 vmask = fast_valid_mask(lane, p.S);
+                const u32 loff = lane * 16u < p.Spad - 16u ? lane * 16u : p.Spad - 16u;
+                for (u32 ci = uniform32(tid >> 6); ci < ncand; ci += T / 64) {
+                    const u32 desc = uniform32((u32)clist[ci]);
+                    const u32 idx0 = desc & 0x7ffu, w = desc >> 11;
+                    const uint8_t* c0p = colbuf + (size_t)idx0 * p.Spad;
+                    const uint4 col0 = *reinterpret_cast<const uint4*>(c0p + loff);
+                    FastGroups G;
+                    G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
+                    G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
+                    bool ok;
+                    if (w == 1u) ok = fast_group_dna1(col0, lane < p.S ? (u32)c0p[lane] : 0u, vmask, lane, p.S, G);
+                    else {
+                        auto load_col = [&](u32 c) -> uint4 { return *reinterpret_cast<const uint4*>(c0p + (size_t)c * p.Spad + loff); };
+                        ok = fast_group_dnakeys<1>(load_col, w, col0, lane, vmask, G) > 0;
+                    }
+                    const u32 textlen = 1u + G.k + G.sumlen;             // "{" + strings + separators / "}"
+                    ok = ok && G.k <= 16u && textlen <= REC_TEXT_MAX;
+                    const u64 slot = slot_base + idx0;
+                    if (p.dbg & 64u) {
+                        if (lane == 0 && !ok) p.rec_info[slot] = 0;
+                    } else if (ok) {
+                        uint8_t* rec = p.recf + slot * (u64)p.recf_stride;
+                        if (lane < nl) {
+                            if (G.k <= 4u) *reinterpret_cast<u32*>(rec + lane * 4u) = pack_gid2(G.gid, vmask);
+                            else *reinterpret_cast<uint2*>(rec + lane * 8u) = pack_gid4(G.gid, vmask);
+                        }
+                        uint8_t* t = rec + p.recf_gid + 4;
+                        if (w == 1u) {                             // lane g holds string g's letter (0: the empty string)
+                            const u32 c = lane < G.k ? (u32)G.key_lo : 0u;
+                            const u64 nz = ballot64(c != 0);
+                            const u32 at = 1u + lane + mbcnt(nz);
+                            if (lane < G.k) {
+                                if (c) t[at] = (uint8_t)c;
+                                t[at + (c ? 1u : 0u)] = lane + 1u < G.k ? ',' : '}';
+                            }
+                        } else {                                   // lane g holds string g as 3-bit classes
+                            const u32 mine = lane < G.k ? G.len + 1u : 0u;
+                            const u32 at = 1u + wave_scan_incl(mine) - mine;
+                            const u32 sk = (u32)G.key_lo, sk2 = (u32)(G.key_lo >> 32);     // ten letters per dword
+                            if (lane < G.k) {
+                                for (u32 i = 0; i < G.len; i++)
+                                    t[at + i] = (uint8_t)__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO,
+                                                                               i < 10u ? (sk >> (3u * i)) & 7u : (sk2 >> (3u * (i - 10u))) & 7u);
+                                t[at + G.len] = lane + 1u < G.k ? ',' : '}';
+                            }
+                        }
+                        if (lane == 0) {
+                            t[0] = '{';
+                            *reinterpret_cast<u32*>(rec + p.recf_gid) = G.k | (textlen << 8);
+                            p.rec_info[slot] = G.k | (textlen << 8) | (G.k > 4u ? 1u << 30 : 0u) | (1u << 31);
+                        }
+                    } else {                                       // not for this path: its columns go to vc after all
+                        if (lane == 0) p.rec_info[slot] = 0;
+                        for (u32 c = 0; c < w; c++)
+                            for (u32 o = lane * 16u; o < p.Spad; o += 1024u)
+                                *reinterpret_cast<uint4*>(p.vc + (slot + c) * (u64)p.Spad + o) =
+                                    *reinterpret_cast<const uint4*>(c0p + (size_t)c * p.Spad + o);
+                    }
+                }
+            }
+        } } else
         for (u32 b0 = 0; b0 < nv || b0 == 0; b0 += cap) {
             if (V16 && nv) {
                 u32 idx = pre_of(j);
@@ -501,6 +971,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                                    ((u64)D[4 * tid + 3] << 48);
                         p.Vraw[wi] = bits;
                         p.word_slot[wi] = slot_base + pre_of(4 * tid);
+                        if (p.fuse) p.Fraw[wi] = 0;
                     }
                 }
             }
@@ -1028,7 +1499,6 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
 //   Text (k_emit_fast): ids of rows 0..127 are placed one row per lane (mixed token lengths), ids 129.. by
 //   the lane that owns the 16 rows: per-lane cursors in LDS, one ds_add_rtn + one aligned ds_write_b32 per id.
 // ---------------------------------------------------------------------------------------------
-constexpr int KCAP = 64;                  // distinct strings per fast segment (group g lives in lane g)
 constexpr u64 META_REC = 1ull << 63;      // the segment has a grouping record; low 40 bits = record index
 constexpr u64 META_KIND4 = 1ull << 62;    // 4-bit group ids (5..16 strings), else 2-bit
 constexpr u64 META_INLINE = 1ull << 61;   // the .eds text of the segment is in the record
@@ -1038,25 +1508,42 @@ constexpr u64 CNT_SCATTER = 1ull << 63;   // count-list descriptor: ncol << 48 |
 constexpr u64 CNT_SLOT = (1ull << 48) - 1;
 // record header (behind the group ids): +0 u32 k | textlen << 8 | ncol << 16;  +8 u64 slot0 | CNT_SCATTER;
 // +16 u16 rep[16] (first row of every string);  +48 text[80]
-constexpr u32 REC_H_SLOT = 8, REC_H_REP = 16, REC_H_TEXT = 144, REC_TEXT_MAX = 64;   // rep[64] ends at 144
+constexpr u32 REC_H_SLOT = 8, REC_H_REP = 16;
 
-// thread per segment: sizes of common segments; a variant segment of pure variant columns gets its column
-// descriptor into cnt_meta[vi] (vi = its ordinal among the variant segments = its record index) for the
-// wave-per-segment grouping kernel, the others (descriptor 0) go to the generic kernels
+// thread per segment: sizes of common segments and of the variant segments the column scan grouped itself; a
+// variant segment of pure variant columns goes on the work list of the wave-per-segment grouping kernel (its
+// ordinal vi among the variant segments = its record index, and its column descriptor), the others go to the
+// generic kernels
 __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
 {
     const MsaView& mv = p.mv;
     const u64 nseg = *p.nseg_ptr;
     const u64 p0 = mv.vbit(0) ? 0 : 1;                   // variant and common segments alternate
-    for (u64 seg = blockIdx.x * (u64)blockDim.x + threadIdx.x; seg < nseg; seg += (u64)gridDim.x * blockDim.x) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) mv.hdr->nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
+    const u64 stride = (u64)gridDim.x * blockDim.x, rounds = (nseg + stride - 1) / stride;
+    for (u64 rd = 0; rd < rounds; rd++) {
+        const u64 seg = rd * stride + blockIdx.x * (u64)blockDim.x + threadIdx.x;
+        u64 work_vi = 0, work_cm = 0, work_wide = 0;
+        if (seg < nseg) do {
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         if (!mv.vbit(a)) {
             p.eds_len[seg] = 2 + (b - a);
             p.seds_len[seg] = 3;
             p.segmeta[seg] = 0;
-            continue;
+            break;
         }
         const u64 vi = (seg - p0) >> 1;
+        if (p.Fraw && ((p.Fraw[a >> 6] >> (a & 63)) & 1ull)) {           // a run the column scan grouped itself?
+            const u64 slot = mv.slot(a);
+            const u32 info = p.rec_info[slot];
+            if (info >> 31) {
+                p.eds_len[seg] = (info >> 8) & 0xffu;
+                p.seds_len[seg] = (u64)(info & 0xffu) + p.tok_total;
+                p.segmeta[seg] = META_REC | META_INLINE | ((info >> 30) & 1u ? META_KIND4 : 0) | slot;
+                work_wide = (info >> 30) & 1u;
+                break;
+            }
+        }
         u64 cm = 0;                                       // 0: generic kernels
         const u64 ncol = b - a;
         if (ncol <= 64) {
@@ -1069,304 +1556,38 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
             if (pure) cm = (ncol << 48) | s0 | (contig ? 0 : CNT_SCATTER);
         }
         if (!cm) p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;        // too wide or mixed columns
-        p.cnt_meta[vi] = cm;
         p.segmeta[seg] = 0;                               // k_seg_group fills it in
-    }
-}
-
-__device__ __forceinline__ uint32_t bytes_ne_mask(uint32_t a, uint32_t b)   // 0xFF where bytes differ
-{
-    uint32_t x = a ^ b;
-    uint32_t h = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // 0x80 where the bytes differ
-    return h | (h - (h >> 7));              // -> 0xFF; (h >> 7) * 0xff would be a quarter-rate v_mul_lo_u32
-}
-__device__ __forceinline__ uint4 bytes_eq_mask(const uint4& a, uint32_t cccc)
-{
-    return make_uint4(~bytes_ne_mask(a.x, cccc), ~bytes_ne_mask(a.y, cccc), ~bytes_ne_mask(a.z, cccc),
-                      ~bytes_ne_mask(a.w, cccc));
-}
-__device__ __forceinline__ bool any4(const uint4& v) { return (v.x | v.y | v.z | v.w) != 0; }
-// does this lane hold a NUL byte in one of its existing rows?
-__device__ __forceinline__ bool any_nul(const uint4& c, const uint4& vmask)
-{
-    const uint4 z = bytes_eq_mask(c, 0u);
-    return ((z.x & vmask.x) | (z.y & vmask.y) | (z.z & vmask.z) | (z.w & vmask.w)) != 0;
-}
-__device__ __forceinline__ u32 first_byte_index(const uint4& m)   // m bytes are 0x00 / 0xFF
-{
-    return m.x ? (u32)__builtin_ctz(m.x) >> 3
-               : m.y ? 4u + ((u32)__builtin_ctz(m.y) >> 3)
-                     : m.z ? 8u + ((u32)__builtin_ctz(m.z) >> 3) : m.w ? 12u + ((u32)__builtin_ctz(m.w) >> 3) : 16u;
-}
-// byte `idx` (wave-uniform) of lane `leader`'s 16-byte vector, as a wave-uniform value
-__device__ __forceinline__ u32 leader_byte(const uint4& v, int leader, u32 idx)
-{
-    const u32 x = (u32)__builtin_amdgcn_readlane((int)v.x, leader), y = (u32)__builtin_amdgcn_readlane((int)v.y, leader);
-    const u32 z = (u32)__builtin_amdgcn_readlane((int)v.z, leader), w = (u32)__builtin_amdgcn_readlane((int)v.w, leader);
-    const u32 d = idx < 8 ? (idx < 4 ? x : y) : (idx < 12 ? z : w);
-    return (d >> ((idx & 3) * 8)) & 0xffu;
-}
-// '-' and '\n' contribute nothing to a row's string (msa_transforms.cpp:283): normalise to 0
-template <bool CHECK_NL>
-__device__ __forceinline__ uint4 normalise_col(const uint4& c, const uint4& vmask, u32& saw_nl)
-{
-    uint4 gap = bytes_eq_mask(c, 0x2d2d2d2du);
-    if (CHECK_NL) {
-        uint4 nl = bytes_eq_mask(c, 0x0a0a0a0au);
-        if (any4(make_uint4(nl.x & vmask.x, nl.y & vmask.y, nl.z & vmask.z, nl.w & vmask.w))) saw_nl = 1;
-        gap.x |= nl.x; gap.y |= nl.y; gap.z |= nl.z; gap.w |= nl.w;
-    }
-    return make_uint4(c.x & ~gap.x, c.y & ~gap.y, c.z & ~gap.z, c.w & ~gap.w);
-}
-
-struct FastGroups {
-    uint4 gid;            // byte i = group of row 16*lane+i (0xFF: no such row)
-    u32 k;                // number of distinct strings (wave-uniform)
-    u32 sumlen;           // sum of their lengths
-    // lane g holds the state of group g
-    u64 key_lo, key_hi;   // the group's gap-stripped string (packed) or its hash, + length
-    u32 rep;              // representative row (first row of the group in row order)
-    u32 len;              // length of the group's string
-};
-
-// lane-private validity mask: byte i = 0xFF iff row 16*lane+i exists
-__device__ __forceinline__ uint4 fast_valid_mask(u32 lane, u32 S)
-{
-    const u32 base = lane * 16u;
-    const u32 n = S > base ? (S - base < 16u ? S - base : 16u) : 0u;       // existing rows of this lane
-    auto word = [&](u32 o) -> uint32_t { return n >= o + 4u ? 0xffffffffu : (n > o ? (1u << (8u * (n - o))) - 1u : 0u); };
-    return make_uint4(word(0), word(4), word(8), word(12));
-}
-
-// assign the rows in `eq` to the group with key (klo,khi): an existing one or a new one.
-// Returns false when KCAP is exceeded.
-__device__ __forceinline__ bool fast_assign(FastGroups& G, uint4& rm, const uint4& eq, u64 klo, u64 khi,
-                                            u32 len, u32 lane, u32 rep_row)
-{
-    const u64 hit = ballot64(lane < G.k && G.key_lo == klo && G.key_hi == khi);
-    u32 gsel;
-    if (hit) gsel = (u32)__builtin_ctzll(hit);
-    else {
-        if (G.k >= (u32)KCAP) return false;
-        gsel = G.k;
-        if (lane == gsel) { G.key_lo = klo; G.key_hi = khi; G.rep = rep_row; G.len = len; }
-        G.k++;
-        G.sumlen += len;
-    }
-    const uint32_t gg = gsel * 0x01010101u;
-    G.gid.x = (G.gid.x & ~eq.x) | (eq.x & gg); G.gid.y = (G.gid.y & ~eq.y) | (eq.y & gg);
-    G.gid.z = (G.gid.z & ~eq.z) | (eq.z & gg); G.gid.w = (G.gid.w & ~eq.w) | (eq.w & gg);
-    rm.x &= ~eq.x; rm.y &= ~eq.y; rm.z &= ~eq.z; rm.w &= ~eq.w;
-    return true;
-}
-
-// signature weights of the multi-column grouping: W_j(c), 24 bit, odd.  A compile-time table (read
-// with scalar loads) instead of two v_mul_lo_u32 per weight.
-struct FastWeights {
-    u32 v[64 * 3];
-    constexpr FastWeights() : v{} {
-        for (u32 c = 0; c < 64; c++)
-            for (u32 j = 0; j < 3; j++) {
-                u32 x = (c + 1u) * 0x9e3779b1u + (j + 1u) * 0x85ebca77u;
-                x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
-                v[c * 3 + j] = (x | 1u) & 0xffffffu;
-            }
-    }
-};
-__device__ const FastWeights FAST_W{};
-
-template <int CTRL, int ROWMASK> __device__ __forceinline__ u32 dpp_move0(u32 v)
-{
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);   // lanes without a source get 0
-}
-// XOR / OR of v over the 64 lanes, wave-uniform (DPP row shifts and broadcasts; lane 63 ends up with all)
-__device__ __forceinline__ u32 wave_xor_all(u32 v)
-{
-    v ^= dpp_move0<0x111, 0xf>(v);       // row_shr:1
-    v ^= dpp_move0<0x112, 0xf>(v);       // row_shr:2
-    v ^= dpp_move0<0x114, 0xf>(v);       // row_shr:4
-    v ^= dpp_move0<0x118, 0xf>(v);       // row_shr:8   -> lane 15 of every row: the row's XOR
-    v ^= dpp_move0<0x142, 0xa>(v);       // row_bcast:15 -> rows 1, 3
-    v ^= dpp_move0<0x143, 0xc>(v);       // row_bcast:31 -> rows 2, 3
-    return (u32)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ u32 wave_or_all(u32 v)
-{
-    v |= dpp_move0<0x111, 0xf>(v); v |= dpp_move0<0x112, 0xf>(v); v |= dpp_move0<0x114, 0xf>(v);
-    v |= dpp_move0<0x118, 0xf>(v); v |= dpp_move0<0x142, 0xa>(v); v |= dpp_move0<0x143, 0xc>(v);
-    return (u32)__builtin_amdgcn_readlane((int)v, 63);
-}
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ u32 wave_scan_incl(u32 v)
-{
-    v += dpp_move0<0x111, 0xf>(v);       // row_shr:1
-    v += dpp_move0<0x112, 0xf>(v);       // row_shr:2
-    v += dpp_move0<0x114, 0xf>(v);       // row_shr:4
-    v += dpp_move0<0x118, 0xf>(v);       // row_shr:8
-    v += dpp_move0<0x142, 0xa>(v);       // row_bcast:15 -> rows 1, 3
-    v += dpp_move0<0x143, 0xc>(v);       // row_bcast:31 -> rows 2, 3
-    return v;
-}
-// minimum of v over lanes 0..7 (wave-uniform)
-__device__ __forceinline__ u32 min_lanes8(u32 v)
-{
-    u32 t;
-    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;
-    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;
-    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;
-    return (u32)__builtin_amdgcn_readlane((int)v, 7);
-}
-
-// class code of the DNA alphabet {A, C, G, T, N, -}: class(b) = ((b >> 1) ^ (b >> 2)) & 7 :
-//   A 0, C 1, G 2, N 4, '-' 5, T 7  (3 and 6 unused).  Any other byte (lower case, IUPAC codes, NUL, a stray
-// newline) fails the reverse lookup (v_perm_b32 = four lookups in an 8-entry table per instruction).
-constexpr u32 DNA_LET_LO = 0x00474341u, DNA_LET_HI = 0x54002d4eu;      // class -> letter (0: unused class)
-__device__ __forceinline__ uint4 dna_classes(const uint4& x)
-{
-    return make_uint4(((x.x >> 1) ^ (x.x >> 2)) & 0x07070707u, ((x.y >> 1) ^ (x.y >> 2)) & 0x07070707u,
-                      ((x.z >> 1) ^ (x.z >> 2)) & 0x07070707u, ((x.w >> 1) ^ (x.w >> 2)) & 0x07070707u);
-}
-__device__ __forceinline__ u32 dna_bad(const uint4& x, const uint4& cls, const uint4& vmask)
-{
-    return ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.x) ^ x.x) & vmask.x) |
-           ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.y) ^ x.y) & vmask.y) |
-           ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.z) ^ x.z) & vmask.z) |
-           ((__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO, cls.w) ^ x.w) & vmask.w);
-}
-
-// One column over {A, C, G, T, N, -}: the grouping of msa_transforms.cpp:262-293 with byte-table lookups.
-//   rb   = the column's byte of row `lane` (rows 0..63 one per lane: most classes first appear there, and then
-//          their first row is one ballot away)
-// Group ids are the ranks of the classes by first row; group g's state lands in lane g as in fast_assign.
-__device__ __forceinline__ bool fast_group_dna1(const uint4& x, u32 rb, const uint4& vmask, u32 lane, u32 S, FastGroups& G)
-{
-    constexpr u32 OH_LO = 0x08040201u, OH_HI = 0x80402010u;        // class -> 1 << class
-    uint4 cls = dna_classes(x);
-    if (ballot64(dna_bad(x, cls, vmask) != 0)) return false;
-    // classes present in this lane's rows, and in the column
-    u32 pl = (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.x) & vmask.x) | (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.y) & vmask.y) |
-             (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.z) & vmask.z) | (__builtin_amdgcn_perm(OH_HI, OH_LO, cls.w) & vmask.w);
-    pl |= pl >> 16; pl |= pl >> 8; pl &= 0xffu;
-    const u32 P = wave_or_all(pl);
-    const u32 rc = lane < S ? (((rb >> 1) ^ (rb >> 2)) & 7u) : 8u;  // class of row `lane`
-    // first row of every class: lane c keeps class c's
-    u32 firstv = 0xffffffffu;
-    for (u32 mm = P; mm; mm &= mm - 1) {
-        const u32 c = (u32)__builtin_ctz(mm);
-        const u64 b = ballot64(rc == c);
-        u32 f;
-        if (b) f = (u32)__builtin_ctzll(b);
-        else {                                             // not among the first 64 rows
-            const int L = __builtin_ctzll(ballot64(((pl >> c) & 1u) != 0));
-            uint4 e = bytes_eq_mask(cls, c * 0x01010101u);
-            e.x &= vmask.x; e.y &= vmask.y; e.z &= vmask.z; e.w &= vmask.w;
-            f = 16u * (u32)L + (u32)__builtin_amdgcn_readlane((int)first_byte_index(e), L);
-        }
-        firstv = lane == c ? f : firstv;
-    }
-    cls.x |= ~vmask.x; cls.y |= ~vmask.y; cls.z |= ~vmask.z; cls.w |= ~vmask.w;   // rows that do not exist: 0xFF
-    // classes in order of first row -> group ids; table class -> group for the lookup below
-    u64 lut = ~0ull;
-    u32 g = 0, sumlen = 0;
-    G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
-    for (u32 rem = P; rem; g++) {
-        const u32 mn = min_lanes8(firstv);
-        const u32 c = (u32)__builtin_ctzll(ballot64(lane < 8u && firstv == mn));
-        const u32 letter = c == 5u ? 0u : (u32)((((u64)DNA_LET_HI << 32) | DNA_LET_LO) >> (8u * c)) & 0xffu;
-        lut = (lut & ~(0xffull << (8u * c))) | ((u64)g << (8u * c));
-        if (lane == g) { G.key_lo = letter; G.rep = mn; G.len = letter ? 1u : 0u; }
-        sumlen += letter ? 1u : 0u;
-        firstv = lane == c ? 0xffffffffu : firstv;
-        rem &= ~(1u << c);
-    }
-    G.k = g; G.sumlen = sumlen;
-    const u32 lut_lo = (u32)lut, lut_hi = (u32)(lut >> 32);
-    G.gid = make_uint4(__builtin_amdgcn_perm(lut_hi, lut_lo, cls.x), __builtin_amdgcn_perm(lut_hi, lut_lo, cls.y),
-                       __builtin_amdgcn_perm(lut_hi, lut_lo, cls.z), __builtin_amdgcn_perm(lut_hi, lut_lo, cls.w));
-    return true;
-}
-
-// the not yet grouped row that comes first in row order (lane, byte): its lane and byte index (uniform)
-__device__ __forceinline__ bool first_remaining(const uint4& rm, int& leader, u32& i0)
-{
-    const u64 b = ballot64(any4(rm));
-    if (!b) return false;
-    leader = __builtin_ctzll(b);
-    i0 = (u32)__builtin_amdgcn_readlane((int)first_byte_index(rm), leader);
-    return true;
-}
-
-// 2..20 columns over {A,C,G,T,N,-}: EXACT raw keys, 3 bits per column (class code), NK dwords of ten columns
-// per row.  Rows with equal keys are byte-identical; a raw group's gap-stripped string is read off its key
-// (drop the gap classes), so no row is re-read.  Returns 1 done, 0 another alphabet, -1 more than KCAP strings.
-template <int NK, class ColPtr>
-__device__ __forceinline__ int fast_group_dnakeys(ColPtr col_ptr, u32 ncol, const uint4& col0, u32 lane, const uint4& vmask,
-                                                  FastGroups& G)
-{
-    u32 key[NK][16];
-#pragma unroll
-    for (int n = 0; n < NK; n++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) key[n][i] = 0;
-    u32 badacc = 0;
-#define EDSX_K(I) key[n][I] |= byte_at<I>(cls) << sh;
-#pragma unroll
-    for (int n = 0; n < NK; n++) {
-        const u32 cbase = 10u * n, cend = ncol < cbase + 10u ? ncol : cbase + 10u;
-        for (u32 c0 = cbase; c0 < cend; c0 += 4) {
-            uint4 cvs[4];                              // four column loads in flight
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                cvs[j] = make_uint4(0, 0, 0, 0);
-                if (c0 + j < cend) cvs[j] = (c0 + j == 0) ? col0 : load16u(col_ptr(c0 + j));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (c0 + j < cend) {
-                    const uint4 x = cvs[j];
-                    const uint4 cls = dna_classes(x);
-                    badacc |= dna_bad(x, cls, vmask);
-                    const u32 sh = 3u * (c0 + j - cbase);
-                    EDSX_K(0) EDSX_K(1) EDSX_K(2) EDSX_K(3) EDSX_K(4) EDSX_K(5) EDSX_K(6) EDSX_K(7)
-                    EDSX_K(8) EDSX_K(9) EDSX_K(10) EDSX_K(11) EDSX_K(12) EDSX_K(13) EDSX_K(14) EDSX_K(15)
-                }
-            }
+        work_vi = vi; work_cm = cm;
+        } while (false);
+        if (seg < nseg && mv.vbit(p.seg_start[seg])) {
+            const u64 vi = (seg - p0) >> 1;
+            p.cnt_meta[vi] = work_cm; p.cnt_flag[vi] = work_cm ? 1 : 0; p.wide_flag[vi] = work_wide;
         }
     }
-#undef EDSX_K
-    if (ballot64(badacc != 0)) return 0;
-    uint4 rm = vmask;
-    int leader;
-    u32 i0;
-    while (first_remaining(rm, leader, i0)) {
-        u32 rk[NK];
-#pragma unroll
-        for (int n = 0; n < NK; n++) {
-            u32 mk = 0;
-#pragma unroll
-            for (int i = 0; i < 16; i++) mk = (i0 == (u32)i) ? key[n][i] : mk;
-            rk[n] = (u32)__builtin_amdgcn_readlane((int)mk, leader);
-        }
-        uint32_t e[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            bool same = key[0][i] == rk[0];
-            if (NK > 1) same = same && key[NK - 1][i] == rk[NK - 1];
-            if (same) e[i >> 2] |= 0xffu << ((i & 3) * 8);
-        }
-        const uint4 eq = make_uint4(e[0] & rm.x, e[1] & rm.y, e[2] & rm.z, e[3] & rm.w);
-        // the group's string: its key without the gap classes; lane = column
-        u32 cl = 5u;
-        if (lane < ncol) cl = ((lane < 10u ? rk[0] : rk[NK - 1]) >> (3u * (lane < 10u ? lane : lane - 10u))) & 7u;
-        const u64 nz = ballot64(cl != 5u);
-        const u32 len = (u32)__builtin_popcountll(nz), pos = mbcnt(nz);
-        u32 klo = 0, khi = 0;                              // 3 bits per letter, ten letters per dword
-        if (cl != 5u) { if (pos < 10u) klo = cl << (3u * pos); else khi = cl << (3u * (pos - 10u)); }
-        klo = wave_or_all(klo);
-        if (NK > 1) khi = wave_or_all(khi);
-        if (!fast_assign(G, rm, eq, ((u64)khi << 32) | klo, (u64)len << 32, len, lane, (u32)leader * 16u + i0)) return -1;
+}
+
+// the heavy grouping kernel's list: the items the light one flagged
+__global__ void __launch_bounds__(256) k_heavy_scatter(FastParams p, const u64* __restrict__ pos)
+{
+    const u64 n = *p.cnt_n, tot = *p.heavy_n;
+    for (u64 it = blockIdx.x * (u64)blockDim.x + threadIdx.x; it < n; it += (u64)gridDim.x * blockDim.x) {
+        const u64 a = pos[it], b = it + 1 < n ? pos[it + 1] : tot;
+        if (a != b) { p.heavy_vi[a] = p.cnt_vi[it]; p.heavy_cm[a] = p.cnt_cm[it]; }
     }
-    return 1;
+}
+
+// work list of the grouping kernel: the variant segments with a column descriptor, compacted with a scan of the
+// flags (no atomics: 4 M appends to one counter would take milliseconds)
+__global__ void __launch_bounds__(256) k_work_scatter(FastParams p, const u64* __restrict__ pos, const u64* __restrict__ nvs_ptr)
+{
+    const u64 nvs = *nvs_ptr;
+    for (u64 vi = blockIdx.x * (u64)blockDim.x + threadIdx.x; vi < nvs; vi += (u64)gridDim.x * blockDim.x) {
+        const u64 cm = p.cnt_meta[vi];
+        if (cm) { const u64 i = pos[vi]; p.cnt_vi[i] = vi; p.cnt_cm[i] = cm; }
+        const u64 wpos = p.wide_flag[vi];               // (exclusive scan in place: position; a set flag = the next one is larger)
+        const u64 wnext = vi + 1 < nvs ? p.wide_flag[vi + 1] : *p.wide_count;
+        if (wnext != wpos) p.wide_list[wpos] = vi;
+    }
 }
 
 // Group the rows of a fast segment (msa_transforms.cpp:262-293: distinct gap-stripped strings in
@@ -1379,9 +1600,11 @@ __device__ __forceinline__ int fast_group_dnakeys(ColPtr col_ptr, u32 ncol, cons
 //                grouping is exact; raw groups that spell the same string are joined by their
 //                stripped string (verbatim key up to 12 letters; longer strings that hash alike send
 //                the segment to the generic kernels).  NUL bytes (msa_transforms.cpp:282) -> generic.
-template <bool CHECK_NL>
-__device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 cmeta, const uint4& col0, u32 rb, u32 lane,
-                                           const uint4& vmask, FastGroups& G, u32& saw_nl)
+// HEAVY false: one column, or 2..10 columns over the DNA alphabet; everything else returns 2 (= try the heavy
+// instantiation, which needs twice the registers).  1 = grouped, 0 = generic kernels.
+template <bool CHECK_NL, bool HEAVY>
+__device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmeta, const uint4& col0, u32 rb, u32 lane,
+                                          const uint4& vmask, FastGroups& G, u32& saw_nl)
 {
     const u32 ncol = (u32)(cmeta >> 48) & 0xffu;
     uint4 rm = vmask;
@@ -1391,37 +1614,54 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 cme
     u32 i0;
 
     if (ncol == 1) {
-        if (fast_group_dna1(col0, rb, vmask, lane, mv.S, G)) return true;
+        if (fast_group_dna1(col0, rb, vmask, lane, mv.S, G)) return 1;
         G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
         G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
         // a NUL byte ends the row's string in the reference (msa_transforms.cpp:282): exact kernels only
-        if (ballot64(any_nul(col0, vmask))) return false;
+        if (ballot64(any_nul(col0, vmask))) return 0;
         const uint4 col = normalise_col<CHECK_NL>(col0, vmask, saw_nl);
         while (first_remaining(rm, leader, i0)) {
             const u32 c = leader_byte(col, leader, i0);
             uint4 eq = bytes_eq_mask(col, c * 0x01010101u);
             eq.x &= rm.x; eq.y &= rm.y; eq.z &= rm.z; eq.w &= rm.w;
-            if (!fast_assign(G, rm, eq, (u64)c, 0ull, c ? 1u : 0u, lane, (u32)leader * 16u + i0)) return false;
+            if (!fast_assign(G, rm, eq, (u64)c, 0ull, c ? 1u : 0u, lane, (u32)leader * 16u + i0)) return 0;
         }
-        return true;
+        return 1;
     }
 
     const u64 slot0 = cmeta & CNT_SLOT;
     const bool scatter = (cmeta & CNT_SCATTER) != 0;
     const u32 loff = lane * 16u < mv.Spad - 16u ? lane * 16u : mv.Spad - 16u;     // lanes without rows stay inside the column
     const uint8_t* cbase = mv.vc + slot0 * (u64)mv.Spad + loff;
+    // A segment whose slots are not consecutive crosses a tile edge of the column scan (once: it has at most 64
+    // columns): the columns from the edge on have the slots word_slot[edge / 64] + 0, 1, ..  (one-line rows)
+    u32 nA = ncol;
+    const uint8_t* cbaseB = cbase;
+    const bool two = scatter && mv.lw == 0 && mv.tileW != 0;
+    if (two) {
+        const u64 bnd = (seg_a / mv.tileW + 1) * mv.tileW;
+        nA = (u32)(bnd - seg_a);
+        cbaseB = mv.vc + uniform64(mv.word_slot[bnd >> 6]) * (u64)mv.Spad + loff;
+    }
     auto col_ptr = [&](u32 c) -> const uint8_t* {
+        if (two) return c < nA ? cbase + (u64)c * mv.Spad : cbaseB + (u64)(c - nA) * mv.Spad;
         return scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + loff : cbase + (u64)c * mv.Spad;
     };
 
+    if (!HEAVY && ncol > 10u) return 2;
     if (ncol <= 20u) {
-        const int r = ncol <= 10u ? fast_group_dnakeys<1>(col_ptr, ncol, col0, lane, vmask, G)
-                                  : fast_group_dnakeys<2>(col_ptr, ncol, col0, lane, vmask, G);
-        if (r) return r > 0;
+        auto load_col = [&](u32 c) -> uint4 { return load16u(col_ptr(c)); };
+        int r;
+        if constexpr (HEAVY) r = ncol <= 10u ? fast_group_dnakeys<1>(load_col, ncol, col0, lane, vmask, G)
+                                             : fast_group_dnakeys<2>(load_col, ncol, col0, lane, vmask, G);
+        else r = fast_group_dnakeys<1>(load_col, ncol, col0, lane, vmask, G);
+        if (r) return r > 0 ? 1 : 0;
+        if (!HEAVY) return 2;
         G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);          // another alphabet: the signature path below
         G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
     }
 
+    if constexpr (HEAVY) {
     // ---- phase A: raw signatures of the 16 rows of this lane: sig_j(row) = sum_c byte(row,c) * W_j(c)
     // (gaps are 0 and contribute nothing; v_mad_u32_u24 is full rate).  Rows with equal normalised
     // columns get equal signatures; a collision of different rows is caught by the comparison in phase B.
@@ -1454,7 +1694,7 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 cme
         }
     }
 #undef EDSX_H
-    if (ballot64(nul != 0)) return false;              // msa_transforms.cpp:282: left to the exact generic kernels
+    if (ballot64(nul != 0)) return 0;                  // msa_transforms.cpp:282: left to the exact generic kernels
 #ifdef EDSX_TEST_WEAK_SIG
     // test-only build: one bit of signature, so that different rows collide all the time and the
     // byte-for-byte verification in phase B is what keeps the groups right
@@ -1488,7 +1728,7 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 cme
                 const u32 lb = leader_byte(cn, leader, i0) * 0x01010101u;
                 mism |= ((cn.x ^ lb) & eq.x) | ((cn.y ^ lb) & eq.y) | ((cn.z ^ lb) & eq.z) | ((cn.w ^ lb) & eq.w);
             }
-            if (ballot64(mism != 0)) return false;
+            if (ballot64(mism != 0)) return 0;
         }
         // the representative's string: lane = column
         const u32 rep_row = (u32)leader * 16u + i0;
@@ -1525,35 +1765,26 @@ __device__ __forceinline__ bool fast_group(const MsaView& mv, u64 seg_a, u64 cme
         // Keys of up to 12 letters are the string itself.  Longer ones are hashed: an equal key then only
         // SUGGESTS that two raw groups (same letters, other gap placement) spell one string, so such a
         // segment is left to the exact generic kernels.
-        if (len > 12u && ballot64(lane < G.k && G.key_lo == klo && G.key_hi == khi)) return false;
-        if (!fast_assign(G, rm, eq, klo, khi, len, lane, rep_row)) return false;
+        if (len > 12u && ballot64(lane < G.k && G.key_lo == klo && G.key_hi == khi)) return 0;
+        if (!fast_assign(G, rm, eq, klo, khi, len, lane, rep_row)) return 0;
     }
-    return true;
+    return 1;
+    } else return 2;
 }
 
-// group-id bytes of this lane's 16 rows -> 2 bits per row (ids 0..3; rows that do not exist: 0)
-__device__ __forceinline__ u32 pack_gid2(const uint4& gid, const uint4& vmask)
-{
-    auto p = [](uint32_t x) -> u32 { x &= 0x03030303u; x |= x >> 6; x |= x >> 12; return x & 0xffu; };
-    return p(gid.x & vmask.x) | (p(gid.y & vmask.y) << 8) | (p(gid.z & vmask.z) << 16) | (p(gid.w & vmask.w) << 24);
-}
-// ... -> 4 bits per row (ids 0..15): rows 0..7 in .x, 8..15 in .y
-__device__ __forceinline__ uint2 pack_gid4(const uint4& gid, const uint4& vmask)
-{
-    auto p = [](uint32_t x) -> u32 { x &= 0x0f0f0f0fu; x |= x >> 4; return (x & 0xffu) | ((x >> 8) & 0xff00u); };
-    return make_uint2(p(gid.x & vmask.x) | (p(gid.y & vmask.y) << 16), p(gid.z & vmask.z) | (p(gid.w & vmask.w) << 16));
-}
-
-// K3 fast: grouping records + sizes of the variant segments with a column descriptor, one wave per segment.
+// K3 fast: grouping records + sizes of the variant segments on the work list, one wave per segment.  The light
+// instantiation (one column / up to ten DNA columns) hands what it cannot do to the heavy one's list.
 // The descriptor and the first column of the wave's next segment are requested one iteration ahead.
-__global__ void __launch_bounds__(256, 4) k_seg_group(FastParams p)
+template <bool HEAVY>
+__global__ void __launch_bounds__(256, HEAVY ? 2 : 4) k_seg_group(FastParams p)
 {
     const MsaView& mv = p.mv;
     if (mv.hdr->status) return;
     const u32 lane = threadIdx.x & 63;
-    const u64 nseg = *p.nseg_ptr;
     const u64 p0 = mv.vbit(0) ? 0 : 1;
-    const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
+    const u64 n = HEAVY ? *p.heavy_n : *p.cnt_n;
+    const u64* lvi = HEAVY ? p.heavy_vi : p.cnt_vi;
+    const u64* lcm = HEAVY ? p.heavy_cm : p.cnt_cm;
     const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
     const uint4 vmask = fast_valid_mask(lane, mv.S);
     const u32 nl = (mv.S + 15u) >> 4;                          // lanes that own rows
@@ -1565,46 +1796,47 @@ __global__ void __launch_bounds__(256, 4) k_seg_group(FastParams p)
     auto load_rb = [&](u64 cm) -> u32 {                        // the first column's byte of row `lane`
         return cm && lane < mv.S ? (u32)mv.vc[(cm & CNT_SLOT) * (u64)mv.Spad + lane] : 0u;
     };
-    u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + uniform32(threadIdx.x >> 6);
-    u64 cmeta = vi < nvs ? uniform64(p.cnt_meta[vi]) : 0;
-    u64 cmeta_n = vi + nw < nvs ? uniform64(p.cnt_meta[vi + nw]) : 0;
+    u64 it = (u64)blockIdx.x * (blockDim.x >> 6) + uniform32(threadIdx.x >> 6);
+    u64 cmeta = it < n ? uniform64(lcm[it]) : 0, vi = it < n ? uniform64(lvi[it]) : 0;
+    u64 cmeta_n = it + nw < n ? uniform64(lcm[it + nw]) : 0, vi_n = it + nw < n ? uniform64(lvi[it + nw]) : 0;
     uint4 col = load_col(cmeta);
     u32 rb = load_rb(cmeta);
-    while (vi < nvs) {
+    while (it < n) {
         const u64 seg = 2 * vi + p0;
         // prefetch: next segment's first column and the descriptor after it
         const uint4 col_n = load_col(cmeta_n);
         const u32 rb_n = load_rb(cmeta_n);
-        const u64 cm_v = p.cnt_meta[vi + 2 * nw < nvs ? vi + 2 * nw : vi];      // scalar after the wait below
-        if (cmeta) {
-            const u32 ncol = (u32)(cmeta >> 48) & 0xffu;
-            FastGroups G;
-            const bool ok = fast_group<true>(mv, (cmeta & CNT_SCATTER) ? uniform64(p.seg_start[seg]) : 0, cmeta, col, rb, lane, vmask, G, saw_nl);
-            // wait for the prefetched column here, before this segment's stores are queued behind it
-            // (vmcnt retires in issue order)
-            asm volatile("" :: "v"(col_n.x), "v"(col_n.y), "v"(col_n.z), "v"(col_n.w), "v"(rb_n), "v"(cm_v));
-            if (ok) {
-                uint8_t* rec = p.rec + vi * (u64)p.rec_stride;
-                if (lane < nl) {
-                    if (G.k <= 4u) *reinterpret_cast<u32*>(rec + lane * 4u) = pack_gid2(G.gid, vmask);
-                    else if (G.k <= 16u) *reinterpret_cast<uint2*>(rec + lane * 8u) = pack_gid4(G.gid, vmask);
-                    else *reinterpret_cast<uint4*>(rec + lane * 16u) = G.gid;
-                }
-                uint8_t* hdr = rec + p.rec_gid;
-                if (lane < G.k) *reinterpret_cast<uint16_t*>(hdr + REC_H_REP + lane * 2u) = (uint16_t)G.rep;
-                if (lane == 0) {
-                    *reinterpret_cast<u32*>(hdr) = G.k | (ncol << 16);
-                    *reinterpret_cast<u64*>(hdr + REC_H_SLOT) = cmeta & (CNT_SLOT | CNT_SCATTER);
-                    p.eds_len[seg] = 2 + (u64)(G.k - 1) + G.sumlen;
-                    p.seds_len[seg] = (u64)G.k + p.tok_total;
-                    p.segmeta[seg] = META_REC | (G.k > 16u ? META_KIND8 : G.k > 4u ? META_KIND4 : 0) | vi;
-                }
-            } else if (lane == 0) {
-                p.slow_list2[atomicAdd(p.slow_count2, 1ull)] = seg;       // the generic kernels take it
+        const u64 i2 = it + 2 * nw < n ? it + 2 * nw : it;
+        const u64 cm_v = lcm[i2], vi_v = lvi[i2];             // scalar after the wait below
+        const u32 ncol = (u32)(cmeta >> 48) & 0xffu;
+        FastGroups G;
+        const int ok = fast_group<true, HEAVY>(mv, (cmeta & CNT_SCATTER) ? uniform64(p.seg_start[seg]) : 0, cmeta, col, rb, lane, vmask, G, saw_nl);
+        // wait for the prefetched column here, before this segment's stores are queued behind it
+        // (vmcnt retires in issue order)
+        asm volatile("" :: "v"(col_n.x), "v"(col_n.y), "v"(col_n.z), "v"(col_n.w), "v"(rb_n), "v"(cm_v), "v"(vi_v));
+        if (ok == 1) {
+            uint8_t* rec = p.rec + vi * (u64)p.rec_stride;
+            if (lane < nl) {
+                if (G.k <= 4u) *reinterpret_cast<u32*>(rec + lane * 4u) = pack_gid2(G.gid, vmask);
+                else if (G.k <= 16u) *reinterpret_cast<uint2*>(rec + lane * 8u) = pack_gid4(G.gid, vmask);
+                else *reinterpret_cast<uint4*>(rec + lane * 16u) = G.gid;
             }
+            uint8_t* hdr = rec + p.rec_gid;
+            if (lane < G.k) *reinterpret_cast<uint16_t*>(hdr + REC_H_REP + lane * 2u) = (uint16_t)G.rep;
+            if (lane == 0) {
+                *reinterpret_cast<u32*>(hdr) = G.k | (ncol << 16);
+                *reinterpret_cast<u64*>(hdr + REC_H_SLOT) = cmeta & (CNT_SLOT | CNT_SCATTER);
+                p.eds_len[seg] = 2 + (u64)(G.k - 1) + G.sumlen;
+                p.seds_len[seg] = (u64)G.k + p.tok_total;
+                p.segmeta[seg] = META_REC | (G.k > 16u ? META_KIND8 : G.k > 4u ? META_KIND4 : 0) | vi;
+                if (G.k > 4u) p.wide_list[atomicAdd(p.wide_count, 1ull)] = vi;
+            }
+        } else if (lane == 0 && !(!HEAVY && ok == 2)) {
+            p.slow_list2[atomicAdd(p.slow_count2, 1ull)] = seg;       // the generic kernels take it
         }
-        const u64 cmeta_nn = vi + 2 * nw < nvs ? uniform64(cm_v) : 0;
-        vi += nw; cmeta = cmeta_n; cmeta_n = cmeta_nn; col = col_n; rb = rb_n;
+        if (!HEAVY && lane == 0) p.cnt_flag[it] = ok == 2 ? 1 : 0;   // for the heavy instantiation (its list: a scan of these flags)
+        const u64 cmeta_nn = it + 2 * nw < n ? uniform64(cm_v) : 0, vi_nn = it + 2 * nw < n ? uniform64(vi_v) : 0;
+        it += nw; cmeta = cmeta_n; cmeta_n = cmeta_nn; vi = vi_n; vi_n = vi_nn; col = col_n; rb = rb_n;
     }
     if (saw_nl) atomicOr(&mv.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));
 }
@@ -1824,8 +2056,282 @@ __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, 
     return total;
 }
 
+// ---- the lean emitter for segments of up to four strings (2-bit group ids): the common case ----------------
+// Rows are split three ways: rows 0..127 and the TAIL rows tb..S-1 (tb = min(992, S rounded down to 16): at most 32
+// rows, ids that may have five bytes) are placed one row per lane with packed DPP scans; rows 128..tb-1 are whole
+// lanes of sixteen 4-byte tokens: no per-row conditions, 2 VALU + ds_add_rtn + ds_write_b32 per id.
+struct alignas(1024) EmitLds2 {
+    u32 tab[4 * 64];                       // [string][lane]: LDS address of this lane's next id of that string
+    u32 gt[96];                            // per string: [0..3] LDS address of its ids, [16..19] of its ids >= 129, [32..35] of
+                                           // its tail ids; [48..51] / [52..55] source / destination of its full 16-byte
+                                           // chunks; [64..87] the ragged ends: (source, destination, bytes) x 8
+    alignas(16) uint8_t stage[EM_STAGE + EM_TRASH];
+};
+struct EmitConst2 {                        // lane constants of the lean emitter
+    u32 tokc[16];                          // "ddd," of rows 16*lane .. +15
+    u32 htok0, htok1, ttok;                // tokens of rows lane, 64 + lane, tb + lane (first four bytes)
+    u32 tsrc, tsh, tlt;                    // tail row: owning lane, shift of its 2-bit field, token length (0: no such row)
+    u32 binc, bmask, trash;                // whole-lane rows: 4 / 0, ~0 / 0 (is this lane one of them), LDS address of its dummy dword
+    u32 nbody;                             // number of those lanes (uniform)
+};
+__device__ __forceinline__ u32 lds_add_rtn(u32 addr, u32 inc)
+{
+    u32 r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r) : "v"(addr), "v"(inc) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_write32(u32 addr, u32 v) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
+
+template <class PreFlush>
+__device__ __forceinline__ void emit_ids2(u32 x0, u32 k, u32 S, u32 lane, const EmitConst2& C, EmitLds2& L, uint8_t* gseds,
+                                          PreFlush pre_flush)
+{
+    const u32 sbase = (u32)(uintptr_t)L.stage, tbase = (u32)(uintptr_t)L.tab;   // LDS byte addresses
+    // ---- the rows placed one per lane: rows lane, 64 + lane and the tail row tb + lane
+    const u32 f = lane & 15u, src = lane >> 4;
+    const u32 g0 = (lane_read(x0, src) >> (2u * f)) & 3u, g1 = (lane_read(x0, src + 4u) >> (2u * f)) & 3u;
+    const u32 gt_ = (lane_read(x0, C.tsrc) >> C.tsh) & 3u;
+    const bool v0 = lane < S, v1 = lane + 64u < S, vt = C.tlt != 0;
+    const u32 tl0 = lane < 9u ? 2u : 3u, tl1 = lane < 35u ? 3u : 4u;       // ids 1-9 | 10-64 and 65-99 | 100-128
+    const u32 f0 = v0 ? tl0 << (g0 * 8u) : 0u, f1 = v1 ? tl1 << (g1 * 8u) : 0u, ft = C.tlt << (gt_ * 8u);
+    const u32 i0 = wave_scan_incl(f0), i1 = wave_scan_incl(f1), it = wave_scan_incl(ft);
+    const u32 ex0 = ((i0 - f0) >> (g0 * 8u)) & 0xffu, ex1 = ((i1 - f1) >> (g1 * 8u)) & 0xffu, ext = ((it - ft) >> (gt_ * 8u)) & 0xffu;
+    const u32 tot0 = (u32)__builtin_amdgcn_readlane((int)i0, 63), tot1 = (u32)__builtin_amdgcn_readlane((int)i1, 63);
+    const u32 tott = (u32)__builtin_amdgcn_readlane((int)it, 63);
+    // ---- the whole lanes: ids of strings 0..2 in this lane (string 3 has the rest), prefix over the lanes
+    const u32 lo = x0 & 0x55555555u, hi = (x0 >> 1) & 0x55555555u;
+    const u32 c1 = (u32)__builtin_popcount(lo & ~hi), c2 = (u32)__builtin_popcount(hi & ~lo), c3 = (u32)__builtin_popcount(lo & hi);
+    const u32 pk = ((16u - c1 - c2 - c3) | (c1 << 10) | (c2 << 20)) & C.bmask;
+    const u32 sp = wave_scan_incl(pk), ep = sp - pk;
+    const u32 totp = (u32)__builtin_amdgcn_readlane((int)sp, 63);
+    const u32 pre0 = ep & 0x3ffu, pre1 = (ep >> 10) & 0x3ffu, pre2 = ep >> 20, pre3 = 16u * (lane - 8u) - pre0 - pre1 - pre2;
+    const u32 t0 = totp & 0x3ffu, t1 = (totp >> 10) & 0x3ffu, t2 = totp >> 20, t3 = 16u * C.nbody - t0 - t1 - t2;
+    // ---- geometry of string `lane` (lanes < k): bytes of its ids up to 128 / of its whole-lane ids / of its tail ids
+    const u32 sh8 = (lane & 3u) * 8u;
+    const u32 hb = ((tot0 >> sh8) & 0xffu) + ((tot1 >> sh8) & 0xffu), tb_ = (tott >> sh8) & 0xffu;
+    const u32 bb = 4u * (lane == 0u ? t0 : lane == 1u ? t1 : lane == 2u ? t2 : t3);
+    const u32 sz = lane < k ? 1u + hb + bb + tb_ : 0u;           // '{' + tokens; the last ',' becomes '}'
+    const u32 rs = lane < k ? (sz + 6u) & ~3u : 0u;              // region: up to 3 bytes of padding in front
+    const u32 pq = rs | (sz << 16);
+    const u32 sq = wave_scan_incl(pq), eq_ = sq - pq;
+    const u32 P = (eq_ & 0xffffu) + ((3u - hb) & 3u);            // (P + 1 + hb) % 4 == 0: the 4-byte tokens are aligned
+    const u32 off = eq_ >> 16;
+    if (lane < k) { L.gt[lane] = sbase + P + 1u; L.gt[16 + lane] = sbase + P + 1u + hb; L.gt[32 + lane] = sbase + P + 1u + hb + bb; }
+    // ---- cursors of the whole lanes (the other lanes: their dummy dword, advanced by 0)
+    {
+        const uint4 b4 = *reinterpret_cast<const uint4*>(&L.gt[16]);
+        const bool body = C.bmask != 0;
+        L.tab[lane] = body ? b4.x + 4u * pre0 : C.trash;
+        L.tab[64 + lane] = body ? b4.y + 4u * pre1 : C.trash;
+        L.tab[128 + lane] = body ? b4.z + 4u * pre2 : C.trash;
+        L.tab[192 + lane] = body ? b4.w + 4u * pre3 : C.trash;
+    }
+    // ---- tokens of rows 0..127 and of the tail rows (single bytes: any alignment)
+    if (v0) {
+        const u32 a = L.gt[g0] + ex0;
+        lds_put2(a, C.htok0);
+        if (lane >= 9u) lds_put1<2>(a, C.htok0 >> 16);
+    }
+    if (v1) {
+        const u32 a = L.gt[g1] + ((tot0 >> (g1 * 8u)) & 0xffu) + ex1;
+        lds_put2(a, C.htok1);
+        lds_put1<2>(a, C.htok1 >> 16);
+        if (lane >= 35u) lds_put1<3>(a, C.htok1 >> 24);
+    }
+    if (vt) {
+        const u32 a = L.gt[32 + gt_] + ext;
+        lds_put2(a, C.ttok);
+        lds_put1<2>(a, C.ttok >> 16);
+        lds_put1<3>(a, C.ttok >> 24);
+        if (C.tlt == 5u) lds_put1<4>(a, (u32)',');
+    }
+    // ---- tokens of the whole lanes: 16 returning ds_add in flight, then 16 aligned ds_write_b32
+    {
+        const u32 lb = tbase + lane * 4u;                     // tab is 1024-aligned: (g << 8) | lb addresses tab[g][lane]
+        u32 a[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) a[j] = lds_add_rtn((((x0 >> (2 * j)) & 3u) << 8) | lb, C.binc);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                                              "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                     :: "memory");
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds_write32(a[j], C.tokc[j]);
+    }
+    // ---- braces (after the tokens: the closing one replaces the last ',')
+    if (lane < k) { L.stage[P] = '{'; L.stage[P + sz - 1u] = '}'; }
+    asm volatile("" ::: "memory");
+    // ---- copy the regions out.  String g: LDS [P, P + sz) -> gseds + off.  hn bytes up to the first 16-byte
+    // boundary of the LDS image, nfull aligned 16-byte chunks, tn bytes behind them.
+    pre_flush();                                                 // (the caller's wait for its prefetched loads)
+    const u32 lead = P & 15u;
+    const u32 hn = lead ? (sz < 16u - lead ? sz : 16u - lead) : 0u;
+    const u32 nfull = (sz - hn) >> 4, tn = (sz - hn) & 15u;
+    const u32 cinc = wave_scan_incl(nfull), cs = cinc - nfull;
+    const u32 T = (u32)__builtin_amdgcn_readlane((int)cinc, 63);
+    const u32 cs1 = (u32)__builtin_amdgcn_readlane((int)cs, 1), cs2 = (u32)__builtin_amdgcn_readlane((int)cs, 2);
+    const u32 cs3 = (u32)__builtin_amdgcn_readlane((int)cs, 3);           // (lanes >= k: no chunks, cs = T)
+    if (lane < k) {
+        L.gt[48 + lane] = P + hn - 16u * cs; L.gt[52 + lane] = off + hn - 16u * cs;
+        u32* e = &L.gt[64 + 6u * lane];
+        e[0] = P; e[1] = off; e[2] = hn;
+        e[3] = P + hn + 16u * nfull; e[4] = off + hn + 16u * nfull; e[5] = tn;
+    }
+    for (u32 t = lane; t < T; t += 64u) {
+        const u32 g = (t >= cs1 ? 1u : 0u) + (t >= cs2 ? 1u : 0u) + (t >= cs3 ? 1u : 0u);
+        const u32 s_ = L.gt[48 + g] + 16u * t, d_ = L.gt[52 + g] + 16u * t;
+        store16u(gseds + d_, *reinterpret_cast<const uint4*>(L.stage + s_));
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {                                // the ragged ends: region = 16 lanes, lane = byte
+        if ((u32)r * 2u < k) {
+            const u32 reg = (u32)r * 4u + (lane >> 4);
+            if (reg < 2u * k) {
+                const u32* e = &L.gt[64 + 3u * reg];
+                const u32 i = lane & 15u;
+                if (i < e[2]) gseds[e[1] + i] = L.stage[e[0] + i];
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
 // what the emitter needs of a segment's record, requested one segment ahead
 struct EmitRec { uint4 x; u32 hv, rep, tb; u64 cm; };
+
+// the segments of up to four strings (records of the column scan: text in the record; records of k_seg_group:
+// text from the first rows in vc)
+__global__ void __launch_bounds__(256, 5) k_emit_fast2(FastParams p)
+{
+    __shared__ EmitLds2 lds_all[4];
+    const MsaView& mv = p.mv;
+    if (mv.hdr->status) return;
+    const u32 lane = threadIdx.x & 63, wv = uniform32(threadIdx.x >> 6);
+    EmitLds2& L = lds_all[wv];
+    const u32 S = mv.S;
+    const u32 tb = S <= 128u ? S : ((S >> 4) << 4 < 992u ? ((S >> 4) << 4 < 128u ? 128u : (S >> 4) << 4) : 992u);   // first tail row
+    EmitConst2 C;
+    auto tok4 = [](u32 id) -> u32 {                        // first four bytes of "<id>,"
+        if (id >= 1000u) return ('0' + id / 1000u) | (('0' + (id / 100u) % 10u) << 8) | (('0' + (id / 10u) % 10u) << 16) | (('0' + id % 10u) << 24);
+        if (id >= 100u) return ('0' + id / 100u) | (('0' + (id / 10u) % 10u) << 8) | (('0' + id % 10u) << 16) | ((u32)',' << 24);
+        if (id >= 10u) return ('0' + id / 10u) | (('0' + id % 10u) << 8) | ((u32)',' << 16);
+        return ('0' + id) | ((u32)',' << 8);
+    };
+#pragma unroll
+    for (int j = 0; j < 16; j++) C.tokc[j] = tok4(lane * 16u + j + 1u);
+    C.htok0 = tok4(lane + 1u); C.htok1 = tok4(lane + 65u);
+    {
+        const u32 row = tb + lane;
+        const bool has = row < S;
+        C.tsrc = has ? row >> 4 : 0u; C.tsh = 2u * (row & 15u);
+        C.tlt = has ? (row + 1u >= 1000u ? 5u : 4u) : 0u;
+        C.ttok = tok4(row + 1u);
+    }
+    C.nbody = tb >= 128u ? (tb >> 4) - 8u : 0u;
+    C.bmask = lane >= 8u && lane < (tb >> 4) ? ~0u : 0u;
+    C.binc = C.bmask ? 4u : 0u;
+    C.trash = (u32)(uintptr_t)L.stage + (u32)EM_STAGE + 4u * lane;
+    const u32 nl = (S + 15u) >> 4;
+    const u64 nseg = *p.nseg_ptr;
+    const u64 p0 = mv.vbit(0) ? 0 : 1;                      // variant and common segments alternate
+    const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
+    const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    auto mine = [](u64 meta) -> bool { return (meta & META_REC) && !(meta & (META_KIND4 | META_KIND8)); };
+    auto load_rec = [&](u64 meta) -> EmitRec {
+        EmitRec r;
+        r.x = make_uint4(0, 0, 0, 0); r.hv = 0; r.rep = 0; r.tb = 0; r.cm = 0;
+        if (mine(meta)) {
+            if (meta & META_INLINE) {                        // grouped by the column scan
+                const uint8_t* rec = p.recf + (meta & META_RECID) * (u64)p.recf_stride;
+                if (lane < nl) r.x.x = *reinterpret_cast<const u32*>(rec + lane * 4u);
+                r.hv = *reinterpret_cast<const u32*>(rec + p.recf_gid);
+                r.tb = rec[p.recf_gid + 4u + lane];
+            } else {
+                const uint8_t* rec = p.rec + (meta & META_RECID) * (u64)p.rec_stride;
+                if (lane < nl) r.x.x = *reinterpret_cast<const u32*>(rec + lane * 4u);
+                const uint8_t* hdr = rec + p.rec_gid;
+                r.hv = *reinterpret_cast<const u32*>(hdr);
+                r.cm = *reinterpret_cast<const u64*>(hdr + REC_H_SLOT);
+                r.rep = *reinterpret_cast<const uint16_t*>(hdr + REC_H_REP + lane * 2u);
+            }
+        }
+        return r;
+    };
+    // Software pipeline over the wave's segments vi, vi+nw, ...: vmcnt retires in issue order, so a wait for a
+    // prefetched record also waits for every store issued before it.  The record of the next segment (and the
+    // descriptor of the one after it) is therefore requested first, the id text of this segment is built in LDS
+    // (no global traffic), and only then the wave waits for the prefetch and issues this segment's stores.
+    u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + wv;
+    const u64 v0i = vi < nvs ? vi : 0, v1i = vi + nw < nvs ? vi + nw : v0i;
+    u64 meta = nvs ? uniform64(p.segmeta[2 * v0i + p0]) : 0, meta_n = nvs ? uniform64(p.segmeta[2 * v1i + p0]) : 0;
+    u64 qoff = nvs ? uniform64(p.seds_len[2 * v0i + p0]) : 0, qoff_n = nvs ? uniform64(p.seds_len[2 * v1i + p0]) : 0;
+    u64 eoff = nvs ? uniform64(p.eds_len[2 * v0i + p0]) : 0, eoff_n = nvs ? uniform64(p.eds_len[2 * v1i + p0]) : 0;
+    EmitRec rc = load_rec(meta);
+    while (vi < nvs) {
+        const u64 seg = 2 * vi + p0;
+        const u64 v2 = vi + 2 * nw < nvs ? vi + 2 * nw : vi;
+        const EmitRec rc_n = load_rec(vi + nw < nvs ? meta_n : 0);
+        const u64 meta_v = p.segmeta[2 * v2 + p0];          // same address in every lane; made scalar
+        const u64 qoff_v = p.seds_len[2 * v2 + p0];         // only after the wait below
+        const u64 eoff_v = p.eds_len[2 * v2 + p0];
+        auto pre_flush = [&]() {
+            asm volatile("" :: "v"(rc_n.x.x), "v"(rc_n.hv), "v"(rc_n.rep), "v"(rc_n.tb), "v"(rc_n.cm), "v"(meta_v), "v"(qoff_v), "v"(eoff_v));
+        };
+        if (mine(meta)) {
+            const u32 hdr0 = uniform32(rc.hv);
+            const u32 k = hdr0 & 0xffu;
+            uint8_t* e = p.eds + eoff;
+            if (meta & META_INLINE) {
+                if (lane < ((hdr0 >> 8) & 0xffu)) e[lane] = (uint8_t)rc.tb;
+            } else {                                         // "{" s0 "," s1 ... "}" from the first rows of the strings
+                const u32 ncol = (hdr0 >> 16) & 0xffu;
+                const u64 cm = uniform64(rc.cm);
+                const u64 slot0 = cm & CNT_SLOT;
+                const bool scatter = (cm & CNT_SCATTER) != 0;
+                const u64 seg_a = scatter ? uniform64(p.seg_start[seg]) : 0;
+                const u32 rep_l = lane < k ? rc.rep : 0u;
+                if (k * ncol <= 64u) {                         // lane = (string, column): one load round trip
+                    const u32 g = lane / ncol, c = lane - g * ncol;
+                    const u32 r = (u32)__shfl((int)rep_l, (int)(g < k ? g : 0u), 64);
+                    u32 ch = 0;
+                    if (g < k) {
+                        const u64 sl = scatter ? mv.slot(seg_a + c) : slot0 + c;
+                        ch = mv.vc[sl * (u64)mv.Spad + r];
+                        if (ch == '-' || ch == '\n') ch = 0;
+                    }
+                    const u64 m = ballot64(ch != 0);
+                    if (lane == 0) e[0] = '{';
+                    if (ch) e[1 + g + mbcnt(m)] = (uint8_t)ch;
+                    if (g < k && c == 0) {                     // separator after string g's letters
+                        const u32 endl = (g + 1) * ncol;
+                        const u64 upto = endl >= 64u ? ~0ull : ((1ull << endl) - 1);
+                        e[1 + g + (u32)__builtin_popcountll(m & upto)] = (g + 1 < k) ? ',' : '}';
+                    }
+                } else {
+                    if (lane == 0) e[0] = '{';
+                    u32 eo = 1;
+                    for (u32 g = 0; g < k; g++) {              // lane = column: the first row's letters
+                        const u32 r = (u32)__builtin_amdgcn_readlane((int)rep_l, (int)g);
+                        u32 ch = 0;
+                        if (lane < ncol) {
+                            const u64 sl = scatter ? mv.slot(seg_a + lane) : slot0 + lane;
+                            ch = mv.vc[sl * (u64)mv.Spad + r];
+                            if (ch == '-' || ch == '\n') ch = 0;
+                        }
+                        const u64 m = ballot64(ch != 0);
+                        const u32 len = (u32)__builtin_popcountll(m);
+                        if (ch) e[eo + mbcnt(m)] = (uint8_t)ch;
+                        if (lane == 0) e[eo + len] = (g + 1 < k) ? ',' : '}';
+                        eo += len + 1;
+                    }
+                }
+            }
+            emit_ids2(rc.x.x, k, S, lane, C, L, p.seds + qoff, pre_flush);
+        } else pre_flush();
+        vi += nw;
+        rc = rc_n; meta = meta_n; qoff = qoff_n; eoff = eoff_n;
+        meta_n = uniform64(meta_v); qoff_n = uniform64(qoff_v); eoff_n = uniform64(eoff_v);
+    }
+}
 
 // WIDE false: the segments of up to four strings (2-bit group ids); true: those of 5..64 strings
 template <bool HAS5, bool WIDE>
@@ -1868,7 +2374,17 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
     auto load_rec = [&](u64 meta) -> EmitRec {
         EmitRec r;
         r.x = make_uint4(0, 0, 0, 0); r.hv = 0; r.rep = 0; r.tb = 0; r.cm = 0;
-        if ((meta & META_REC) && ((meta & (META_KIND4 | META_KIND8)) != 0) == WIDE) {
+        if ((meta & META_REC) && (meta & META_INLINE)) {     // grouped by the column scan: text in the record
+            if (WIDE == ((meta & META_KIND4) != 0)) {
+                const uint8_t* rec = p.recf + (meta & META_RECID) * (u64)p.recf_stride;
+                if (lane < nl) {
+                    if (WIDE) { const uint2 v = *reinterpret_cast<const uint2*>(rec + lane * 8u); r.x.x = v.x; r.x.y = v.y; }
+                    else r.x.x = *reinterpret_cast<const u32*>(rec + lane * 4u);
+                }
+                r.hv = *reinterpret_cast<const u32*>(rec + p.recf_gid);
+                r.tb = rec[p.recf_gid + 4u + lane];
+            }
+        } else if ((meta & META_REC) && ((meta & (META_KIND4 | META_KIND8)) != 0) == WIDE) {
             const uint8_t* rec = p.rec + (meta & META_RECID) * (u64)p.rec_stride;
             if (lane < nl) {
                 if (meta & META_KIND8) r.x = *reinterpret_cast<const uint4*>(rec + lane * 16u);
@@ -1877,11 +2393,8 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
             }
             const uint8_t* hdr = rec + p.rec_gid;
             r.hv = *reinterpret_cast<const u32*>(hdr);
-            if (meta & META_INLINE) r.tb = hdr[REC_H_TEXT + lane];
-            else {
-                r.cm = *reinterpret_cast<const u64*>(hdr + REC_H_SLOT);
-                r.rep = *reinterpret_cast<const uint16_t*>(hdr + REC_H_REP + lane * 2u);
-            }
+            r.cm = *reinterpret_cast<const u64*>(hdr + REC_H_SLOT);
+            r.rep = *reinterpret_cast<const uint16_t*>(hdr + REC_H_REP + lane * 2u);
         }
         return r;
     };
@@ -1889,19 +2402,16 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
     // prefetched record also waits for every store issued before it.  The record of the next segment (and the
     // descriptor of the one after it) is therefore requested first, the id text of this segment is built in LDS
     // (no global traffic), and only then the wave waits for the prefetch and issues this segment's stores.
-    u64 vi = (u64)blockIdx.x * (blockDim.x >> 6) + wv;
-    const u64 v0i = vi < nvs ? vi : 0, v1i = vi + nw < nvs ? vi + nw : v0i;
-    u64 meta = nvs ? uniform64(p.segmeta[2 * v0i + p0]) : 0, meta_n = nvs ? uniform64(p.segmeta[2 * v1i + p0]) : 0;
-    u64 qoff = nvs ? uniform64(p.seds_len[2 * v0i + p0]) : 0, qoff_n = nvs ? uniform64(p.seds_len[2 * v1i + p0]) : 0;
-    u64 eoff = nvs ? uniform64(p.eds_len[2 * v0i + p0]) : 0, eoff_n = nvs ? uniform64(p.eds_len[2 * v1i + p0]) : 0;
-    EmitRec rc = load_rec(meta);
-    while (vi < nvs) {
+    // the wide emitter walks its work list (few segments: no software pipeline)
+    const u64 nwide = *p.wide_count;
+    for (u64 it = (u64)blockIdx.x * (blockDim.x >> 6) + wv; it < nwide; it += nw) {
+        const u64 vi = uniform64(p.wide_list[it]);
         const u64 seg = 2 * vi + p0;
-        const u64 v2 = vi + 2 * nw < nvs ? vi + 2 * nw : vi;
-        const EmitRec rc_n = load_rec(vi + nw < nvs ? meta_n : 0);
-        const u64 meta_v = p.segmeta[2 * v2 + p0];          // same address in every lane; made scalar
-        const u64 qoff_v = p.seds_len[2 * v2 + p0];         // only after the wait below
-        const u64 eoff_v = p.eds_len[2 * v2 + p0];
+        const u64 meta = uniform64(p.segmeta[seg]);
+        const u64 qoff = uniform64(p.seds_len[seg]), eoff = uniform64(p.eds_len[seg]);
+        const EmitRec rc = load_rec(meta);
+        const EmitRec rc_n = rc;
+        const u64 meta_v = 0, qoff_v = 0, eoff_v = 0;
         const bool fast = (meta & META_REC) != 0 && ((meta & (META_KIND4 | META_KIND8)) != 0) == WIDE;
         const u32 hdr0 = uniform32(rc.hv);
         const u32 k = hdr0 & 0xffu, textlen = (hdr0 >> 8) & 0xffu, ncol = (hdr0 >> 16) & 0xffu;
@@ -1991,9 +2501,6 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
                 emit_ids<WIDE ? 2 : 2, HAS5>(rc.x.x, 0u, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush, p.dbg);
             }
         } else pre_flush();
-        vi += nw;
-        rc = rc_n; meta = meta_n; qoff = qoff_n; eoff = eoff_n;
-        meta_n = uniform64(meta_v); qoff_n = uniform64(qoff_v); eoff_n = uniform64(eoff_v);
     }
 }
 
@@ -2055,7 +2562,11 @@ int MsaPipeline::get_timing(const char** names, float* ms, int* counts, int cap)
 
 #define TIMED(name, st, ...) do { launch_timer_begin(name, st); __VA_ARGS__; launch_timer_end(st); } while (0)
 
-MsaPipeline::~MsaPipeline() { clear_timers(); }
+MsaPipeline::~MsaPipeline()
+{
+    clear_timers();
+    if (side_) { (void)hipStreamDestroy(side_); (void)hipEventDestroy(ev_fork_); (void)hipEventDestroy(ev_join_); }
+}
 
 static const char* status_message(u64 st)
 {
@@ -2127,6 +2638,11 @@ void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t s
         break;
     }
     if (h_.status) throw FormatError(status_message(h_.status & ~(u64)ST_VC_OVERFLOW));
+    if (getenv("EDSX_COUNTS"))
+        fprintf(stderr, "[edsx] segments %llu variant %llu | grouping list %llu heavy %llu | wide emit %llu | generic %llu + %llu | fused %d\n",
+                (unsigned long long)(l == 0 ? h_.R : h_.nseg), (unsigned long long)h_.nvs, (unsigned long long)h_.cnt_n,
+                (unsigned long long)h_.heavy_n, (unsigned long long)h_.wide_n, (unsigned long long)h_.slow_n,
+                (unsigned long long)h_.slow_n2, (int)fuse_);
     if (l == 0) h_.nseg = h_.R;
     *eds_bytes = h_.E;
     *seds_bytes = h_.Q;
@@ -2183,8 +2699,23 @@ void MsaPipeline::plan_body(hipStream_t st)
     kp.vc_cap_cols = vc_cap_cols_; kp.Draw = Draw; kp.lw = lw; kp.S = (u32)S; kp.Spad = Spad;
     kp.cpr_log2 = cpr_log2; kp.cap_cols = (u32)(colbuf_bytes / Spad); kp.ntiles = ntiles;
     if (kp.cap_cols == 0) throw FormatError(status_message(ST_TOO_MANY_ROWS));
-    launch_timer_begin("k_scan_extract", st);
     const bool lane_rows = hold && RPT == 16;             // thread rows = 16 consecutive rows = 16 consecutive vc bytes
+    // fused grouping: context length 0 (segments = runs), one-line rows (raw position = column), wave-per-segment code
+    static int fuse_env = -1;
+    if (fuse_env < 0) { const char* e = getenv("EDSX_FUSE"); fuse_env = e ? atoi(e) : 1; }
+    fuse_ = fuse_env && l == 0 && lw == 0 && S <= 1024 && lane_rows && cfg != 2;
+    { const char* e = getenv("EDSX_DBG"); kp.dbg = e ? (u32)atoi(e) : 0u; }
+    kp.fuse = fuse_ ? 1u : 0u; kp.Fraw = nullptr; kp.rec_info = nullptr; kp.recf = nullptr; kp.recf_stride = 0; kp.recf_gid = 0;
+    if (fuse_) {
+        recf_gid_ = (8u * (((u32)S + 15u) / 16u) + 15u) & ~15u;
+        recf_stride_ = (recf_gid_ + 4u + REC_TEXT_MAX + 63u) & ~63u;
+        fraw_.ensure(8 * (nwords_raw + 1));
+        rec_info_.ensure(4 * ((size_t)vc_cap_cols_ + 2));
+        recf_.ensure(((size_t)vc_cap_cols_ + 2) * recf_stride_);
+        kp.Fraw = fraw_.as<u64>(); kp.rec_info = rec_info_.as<u32>(); kp.recf = recf_.as<uint8_t>();
+        kp.recf_stride = recf_stride_; kp.recf_gid = recf_gid_;
+    }
+    launch_timer_begin("k_scan_extract", st);
     if (cfg == 1) {
         if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
         else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
@@ -2234,7 +2765,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     // ---- K3 + K4: per-segment sizes, offsets
     mv_.file = d_msa; mv_.row_start = rows_.as<u64>(); mv_.V = V; mv_.Vraw = vraw_.as<u64>();
     mv_.word_slot = wslot_.as<u64>(); mv_.vc = vc_.as<uint8_t>(); mv_.hdr = dh; mv_.L = L; mv_.lw = lw;
-    mv_.S = (u32)S; mv_.Spad = Spad;
+    mv_.S = (u32)S; mv_.Spad = Spad; mv_.tileW = (u32)W;
     seg_start_p_ = seg_start; hseg_p_ = Hseg; segbase_p_ = segbase; nseg_p_ = d_nseg;
     seg_lds_ = (size_t)18 * S + 64 + (S <= HT_MAX_ROWS ? HtLds::BYTES + 16 : 0);
     seg_lds_ = (seg_lds_ + 15) & ~(size_t)15;
@@ -2261,22 +2792,35 @@ void MsaPipeline::plan_body(hipStream_t st)
         segmeta_.ensure(8 * (L + 2));
         // list 1: too wide or mixed segments (k_seg_meta), list 2: those the grouping kernel gives up on; together
         // at most all variant segments (<= L/2 + 1)
-        slow_list_.ensure(8 * (L + 8));
-        cnt_list_.ensure(8 * (L / 2 + 4));                    // column descriptor per variant segment
+        slow_list_.ensure(8 * 3 * (L / 2 + 4));            // + the wide emitter's list
+        cnt_list_.ensure(8 * 7 * (L / 2 + 4));                // work lists of the grouping kernels (ordinal + column descriptor, twice), descriptor and flag per variant segment
         fp_.mv = mv_; fp_.seg_start = seg_start; fp_.nseg_ptr = d_nseg; fp_.segmeta = segmeta_.as<u64>();
         fp_.eds_len = eds_len_.as<u64>(); fp_.seds_len = seds_len_.as<u64>();
         fp_.slow_list = slow_list_.as<u64>(); fp_.slow_count = &dh->slow_n;
         fp_.slow_list2 = slow_list_.as<u64>() + (L / 2 + 4); fp_.slow_count2 = &dh->slow_n2;
-        fp_.cnt_meta = cnt_list_.as<u64>();
+        fp_.cnt_vi = cnt_list_.as<u64>(); fp_.cnt_cm = fp_.cnt_vi + (L / 2 + 4); fp_.cnt_n = &dh->cnt_n;
+        fp_.heavy_vi = fp_.cnt_cm + (L / 2 + 4); fp_.heavy_cm = fp_.heavy_vi + (L / 2 + 4); fp_.heavy_n = &dh->heavy_n;
+        fp_.cnt_meta = fp_.heavy_cm + (L / 2 + 4); fp_.cnt_flag = fp_.cnt_meta + (L / 2 + 4); fp_.wide_flag = fp_.cnt_flag + (L / 2 + 4);
+        fp_.wide_list = slow_list_.as<u64>() + 2 * (L / 2 + 4); fp_.wide_count = &dh->wide_n;
         fp_.eds = nullptr; fp_.seds = nullptr; fp_.tok_total = tok_total;
         // one record per variant segment; there are at most as many as variant columns
         fp_.rec_stride = rec_stride((u32)S); fp_.rec_gid = rec_gid_bytes((u32)S);
         rec_.ensure(((size_t)std::min<u64>(vc_cap_cols_, L / 2 + 2) + 2) * fp_.rec_stride);
         fp_.rec = rec_.as<uint8_t>();
+        fp_.Fraw = fuse_ ? fraw_.as<u64>() : nullptr; fp_.rec_info = rec_info_.as<u32>();
+        fp_.recf = recf_.as<uint8_t>(); fp_.recf_stride = recf_stride_; fp_.recf_gid = recf_gid_;
         EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, 2 * sizeof(u64), st));
+        EDSX_HIP(hipMemsetAsync(&dh->wide_n, 0, 3 * sizeof(u64), st));     // (wide_n is then set by scan_wide, and added to by k_seg_group)
         TIMED("k_seg_meta", st, hipLaunchKernelGGL(k_seg_meta, dim3(4096), dim3(256), 0, st, fp_));
-        TIMED("k_seg_group", st, hipLaunchKernelGGL(k_seg_group, dim3(persistent_grid(
-                  reinterpret_cast<const void*>(k_seg_group), 256, 0)), dim3(256), 0, st, fp_));
+        TIMED("scan_work", st, exclusive_scan_u64(fp_.cnt_flag, fp_.cnt_flag, &dh->nvs, &dh->cnt_n, scan_tmp_.as<u64>(), st));
+        TIMED("scan_wide", st, exclusive_scan_u64(fp_.wide_flag, fp_.wide_flag, &dh->nvs, &dh->wide_n, scan_tmp_.as<u64>(), st));
+        TIMED("k_work_scatter", st, hipLaunchKernelGGL(k_work_scatter, dim3(2048), dim3(256), 0, st, fp_, fp_.cnt_flag, &dh->nvs));
+        TIMED("k_seg_group", st, hipLaunchKernelGGL(k_seg_group<false>, dim3(persistent_grid(
+                  reinterpret_cast<const void*>(k_seg_group<false>), 256, 0)), dim3(256), 0, st, fp_));
+        TIMED("scan_heavy", st, exclusive_scan_u64(fp_.cnt_flag, fp_.cnt_flag, &dh->cnt_n, &dh->heavy_n, scan_tmp_.as<u64>(), st));
+        TIMED("k_heavy_scatter", st, hipLaunchKernelGGL(k_heavy_scatter, dim3(2048), dim3(256), 0, st, fp_, fp_.cnt_flag));
+        TIMED("k_seg_group_heavy", st, hipLaunchKernelGGL(k_seg_group<true>, dim3(persistent_grid(
+                  reinterpret_cast<const void*>(k_seg_group<true>), 256, 0)), dim3(256), 0, st, fp_));
         sp.list = fp_.slow_list; sp.list_n = fp_.slow_count;
         TIMED("k_seg_count_slow", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
         sp.list = fp_.slow_list2; sp.list_n = fp_.slow_count2;
@@ -2397,25 +2941,32 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_emit_variant),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     if (fast_) {
-        TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
+        // The main emitter (segments of up to four strings) is bound by its stores; the common text, the wide and the
+        // generic emitters are small and latency-bound: they run beside it on a second stream.
+        if (!side_) {
+            EDSX_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+            EDSX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+            EDSX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        }
+        EDSX_HIP(hipEventRecord(ev_fork_, st));
+        EDSX_HIP(hipStreamWaitEvent(side_, ev_fork_, 0));
         FastParams fp = fp_;
         fp.eds = d_eds; fp.seds = d_seds;
         { const char* e = getenv("EDSX_DBG"); fp.dbg = e ? (u32)atoi(e) : 0u; }
-        auto launch_emit = [&](auto kern, const char* name) {
-            TIMED(name, st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
-                                               dim3(256), 0, st, fp));
+        auto launch_emit = [&](auto kern, const char* name, hipStream_t s) {
+            TIMED(name, s, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
+                                              dim3(256), 0, s, fp));
         };
-        if (h_.S >= 1000) {                                   // ids of five bytes exist
-            launch_emit(k_emit_fast<true, false>, "k_emit_fast");
-            launch_emit(k_emit_fast<true, true>, "k_emit_fast_wide");
-        } else {
-            launch_emit(k_emit_fast<false, false>, "k_emit_fast");
-            launch_emit(k_emit_fast<false, true>, "k_emit_fast_wide");
-        }
+        launch_emit(k_emit_fast2, "k_emit_fast", st);
+        TIMED("k_emit_common", side_, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, side_, ep));
+        if (h_.S >= 1000) launch_emit(k_emit_fast<true, true>, "k_emit_fast_wide", side_);      // ids of five bytes exist
+        else launch_emit(k_emit_fast<false, true>, "k_emit_fast_wide", side_);
         ep.list = fp_.slow_list; ep.list_n = fp_.slow_count;
-        TIMED("k_emit_variant_slow", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+        TIMED("k_emit_variant_slow", side_, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, side_, ep));
         ep.list = fp_.slow_list2; ep.list_n = fp_.slow_count2;
-        TIMED("k_emit_variant_slow2", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+        TIMED("k_emit_variant_slow2", side_, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, side_, ep));
+        EDSX_HIP(hipEventRecord(ev_join_, side_));
+        EDSX_HIP(hipStreamWaitEvent(st, ev_join_, 0));
     } else {
         TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
         TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));

@@ -83,8 +83,9 @@ struct MsaHdr {
     u64 slow_n2;       // ... and those the fast kernel gave up on (more than KCAP distinct strings)
     u64 idx_done;      // the speculative parallel row index validated: k_index_rows skips its chain
     u64 idx_bad;       // first row whose speculative header position did not validate
-    u64 cnt_n;         // variant segments handed to the wave-per-segment grouping kernel
-    u64 nrec;          // grouping records written by the column scan itself (fused segments)
+    u64 wide_n;        // variant segments of 5..64 strings (k_seg_group -> wide emitter)
+    u64 cnt_n, heavy_n; // lengths of the grouping kernels' work lists (adjacent to wide_n: cleared together)
+    u64 nvs;           // number of variant segments
 };
 
 // One vc column holds the bytes of one variant column in NATURAL row order: byte r = row r, pitch =
@@ -94,7 +95,7 @@ struct MsaHdr {
 __host__ __device__ inline u32 vc_pitch(u32 S) { return (S + 15u) / 16u * 16u + 16u; }
 
 // grouping record of a variant segment (wave-per-segment kernels, S <= 1024), see msa_device.hip
-constexpr u32 REC_HDR = 256;
+constexpr u32 REC_HDR = 192;      // u32 k | ncol << 16; u64 first slot; u16 first row of each of up to 64 strings
 __host__ __device__ inline u32 rec_gid_bytes(u32 S) { return 16u * ((S + 15u) / 16u); }       // up to 8 bits per row
 __host__ __device__ inline u32 rec_stride(u32 S) { return (rec_gid_bytes(S) + REC_HDR + 63u) & ~63u; }
 
@@ -102,6 +103,7 @@ __host__ __device__ inline u32 rec_stride(u32 S) { return (rec_gid_bytes(S) + RE
 struct MsaView {
     const uint8_t* file; const u64* row_start; const u64* V; const u64* Vraw; const u64* word_slot;
     const uint8_t* vc; MsaHdr* hdr; u64 L, lw; u32 S, Spad;
+    u32 tileW;                              // columns per tile of the column scan: slots are consecutive inside a tile
     __device__ __forceinline__ u64 raw(u64 c) const { return lw ? c + c / lw : c; }
     __device__ __forceinline__ u32 vbit(u64 c) const { return (u32)(V[c >> 6] >> (c & 63)) & 1u; }
     __device__ __forceinline__ u64 slot(u64 c) const
@@ -119,9 +121,15 @@ struct FastParams {
     u64* eds_len; u64* seds_len;            // sizes (count pass) == offsets (emit pass, after the scans)
     u64* slow_list; u64* slow_count;        // variant segments left to the generic kernels (k_seg_meta)
     u64* slow_list2; u64* slow_count2;      // ... added by k_seg_group
-    u64* cnt_meta;                          // column descriptor per variant segment (0: generic kernels)
+    u64* wide_list; u64* wide_count;        // variant segments (ordinals) of 5..64 strings: the wide emitter's work list
+    u64* wide_flag;                         // per variant segment: grouped by the column scan with 5..16 strings (-> wide emitter's list)
+    u64* cnt_meta; u64* cnt_flag;           // per variant segment: column descriptor (0: not for k_seg_group), flag / list position
+    u64* cnt_vi; u64* cnt_cm; u64* cnt_n;   // work list of k_seg_group: ordinal among the variant segments, column descriptor
+    u64* heavy_vi; u64* heavy_cm; u64* heavy_n;   // ... of its heavy instantiation (wide or non-DNA segments)
     uint8_t* eds; uint8_t* seds; u64 tok_total;
     uint8_t* rec; u32 rec_stride, rec_gid;  // grouping records (count -> emit): stride, bytes of the group-id area
+    const u64* Fraw; const u32* rec_info;   // column scan's own groupings: first-column bitmap, k | textlen << 8 | ok << 31 per slot
+    const uint8_t* recf; u32 recf_stride, recf_gid;   // ... and their records (indexed by slot)
     u32 dbg = 0;                            // EDSX_DBG: timing experiments (skips phases; output is then wrong)
 };
 
@@ -164,7 +172,7 @@ private:
     std::vector<TimedKernel> timed_;
 
     DevBuf hdr_, rows_, vraw_, v_, wslot_, vc_, hrun_, hseg_, cnt_, wbase_, segbase_, scan_tmp_,
-           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, cnt_list_, rec_, colbuf_, idx_tmp_;
+           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, cnt_list_, rec_, recf_, rec_info_, fraw_, colbuf_, idx_tmp_;
     u64 vc_cap_cols_ = 0;
 
     // emit-time view
@@ -173,9 +181,12 @@ private:
     const u64* nseg_p_ = nullptr;
     size_t seg_lds_ = 0;
     u32 stage_off_ = 0, stage_cols_ = 0;   // generic kernels: column staging area in their LDS (offset, capacity; 0: none)
-    bool fast_ = false;
+    bool fast_ = false, fuse_ = false;
+    u32 recf_stride_ = 0, recf_gid_ = 0;
     FastParams fp_{};
     int cus_ = 0;
+    hipStream_t side_ = nullptr;            // common text, wide and generic emitters run beside the main emitter
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
 };
 
 } // namespace edsx
