@@ -1,9 +1,6 @@
 """Build libedsx.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
 One object per source under edsparser_amd/build/ (compiled in parallel, only when stale), then one link.
-`libedsx_weaksig.so` is a TEST-ONLY variant: msa_device.hip compiled with -DEDSX_TEST_WEAK_SIG (row signatures
-of the multi-column grouping masked to one bit, so that different rows collide all the time and the byte-for-byte
-verification behind the signatures is what keeps the output right); tests/test_msa_gpu.py runs it against the oracle.
 """
 import os
 import subprocess
@@ -14,7 +11,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libedsx.so")
-LIB_WEAKSIG = os.path.join(HERE, "libedsx_weaksig.so")
 SOURCES = ["msa_device.hip", "merge_device.hip", "vcf_device.hip", "synth.hip", "stats_device.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
@@ -59,18 +55,11 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
             jobs.append((src, obj, []))
-    weak_obj = os.path.join(OBJ, "msa_device_weaksig.o")
-    msa_src = os.path.join(CSRC, "msa_device.hip")
-    if force or _newer(weak_obj, [msa_src] + hdrs):
-        jobs.append((msa_src, weak_obj, ["-DEDSX_TEST_WEAK_SIG"]))
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(lambda j: _compile(j[0], j[1], j[2], verbose), jobs))
     if force or _newer(LIB, objs):
         _link(objs, LIB, verbose)
-    weak_objs = [weak_obj if o.endswith("msa_device.o") else o for o in objs]
-    if force or _newer(LIB_WEAKSIG, weak_objs):
-        _link(weak_objs, LIB_WEAKSIG, verbose)
     return LIB
 
 

@@ -1590,6 +1590,154 @@ __global__ void __launch_bounds__(256) k_work_scatter(FastParams p, const u64* _
     }
 }
 
+// four lookups in a table of 32 bytes (t[2q+1]:t[2q] holds entries 8q .. 8q+7): byte i of the result = table[byte i of g4]
+__device__ __forceinline__ uint32_t lut32(const u32* t, uint32_t g4)
+{
+    const uint32_t sel = g4 & 0x07070707u;
+    const uint32_t h3 = (g4 >> 3) & 0x01010101u, m3 = (h3 << 8) - h3;      // 0xFF where bit 3 of the index is set
+    const uint32_t h4 = (g4 >> 4) & 0x01010101u, m4 = (h4 << 8) - h4;      // ... bit 4
+    const uint32_t e0 = __builtin_amdgcn_perm(t[1], t[0], sel), e1 = __builtin_amdgcn_perm(t[3], t[2], sel);
+    const uint32_t e2 = __builtin_amdgcn_perm(t[5], t[4], sel), e3 = __builtin_amdgcn_perm(t[7], t[6], sel);
+    const uint32_t lo = (e1 & m3) | (e0 & ~m3), hi = (e3 & m3) | (e2 & ~m3);
+    return (hi & m4) | (lo & ~m4);
+}
+
+// ... of 64 bytes
+__device__ __forceinline__ uint32_t lut64(const u32* t, uint32_t g4)
+{
+    const uint32_t h5 = (g4 >> 5) & 0x01010101u, m5 = (h5 << 8) - h5;
+    return (lut32(t + 8, g4) & m5) | (lut32(t, g4) & ~m5);
+}
+
+template <int MAXG> __device__ __forceinline__ uint32_t lutN(const u32* t, uint32_t g4)
+{
+    if constexpr (MAXG <= 8) return __builtin_amdgcn_perm(t[1], t[0], g4);
+    else if constexpr (MAXG <= 16) {
+        const uint32_t sel = g4 & 0x07070707u, h = (g4 >> 3) & 0x01010101u, m = (h << 8) - h;   // 0xFF where the index is >= 8
+        return (__builtin_amdgcn_perm(t[3], t[2], sel) & m) | (__builtin_amdgcn_perm(t[1], t[0], sel) & ~m);
+    } else if constexpr (MAXG <= 32) return lut32(t, g4);
+    else return lut64(t, g4);
+}
+
+// Any alphabet, up to 64 columns: refine the partition of the rows column by column.  All rows start in one
+// raw group; per column every row is compared with the byte of its group's first row (one table lookup per row:
+// v_perm_b32 on the group id), and a group whose rows disagree is split off at its first disagreeing row.  Raw
+// groups are classes of identical rows, exact for every byte value; their gap-stripped strings (the reference
+// ends a row's string at NUL, msa_transforms.cpp:282) are built once from the first rows, and raw groups that
+// spell one string are joined.  More than 64 raw groups, or a NUL inside the segment: generic kernels.
+// Returns 1 grouped, 0 generic kernels (NUL), -1 more than MAXG raw groups.
+template <int MAXG, bool CHECK_NL, class ColPtr, class CellPtr>
+__device__ __forceinline__ int refine_groups(ColPtr col_ptr, CellPtr cell_ptr, u32 ncol, const uint4& col0, u32 lane, const uint4& vmask,
+                                             FastGroups& G, u32& saw_nl, uint8_t* strs)
+{
+    uint4 gid = make_uint4(~vmask.x, ~vmask.y, ~vmask.z, ~vmask.w);        // group 0; rows that do not exist: 0xFF
+    u32 k = 1, rep_l = 0;                               // lane g: first row of raw group g
+    for (u32 c0 = 0; c0 < ncol; c0 += 4) {
+        uint4 cvs[4];                                   // four column loads in flight
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            cvs[j] = make_uint4(0, 0, 0, 0);
+            if (c0 + j < ncol) cvs[j] = (c0 + j == 0) ? col0 : load16u(col_ptr(c0 + j));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (c0 + j >= ncol) continue;
+            const uint4 col = cvs[j];
+            u32 t[MAXG / 4];                                  // byte g & 7 of (t[2q+1]:t[2q]), q = g >> 3: this column's byte of group g's first row
+#pragma unroll
+            for (int i = 0; i < MAXG / 4; i++) t[i] = 0;
+            for (u32 g = 0; g < k; g++) {
+                const u32 r = (u32)__builtin_amdgcn_readlane((int)rep_l, (int)g);
+                const u32 tb = leader_byte(col, (int)(r >> 4), r & 15u) << ((g & 3u) * 8u);
+#pragma unroll
+                for (int i = 0; i < MAXG / 4; i++) if ((g >> 2) == (u32)i) t[i] |= tb;
+            }
+            for (;;) {
+                uint4 ex;
+                if (k <= 8u) {
+                    ex = make_uint4(__builtin_amdgcn_perm(t[1], t[0], gid.x), __builtin_amdgcn_perm(t[1], t[0], gid.y),
+                                    __builtin_amdgcn_perm(t[1], t[0], gid.z), __builtin_amdgcn_perm(t[1], t[0], gid.w));
+                } else ex = make_uint4(lutN<MAXG>(t, gid.x), lutN<MAXG>(t, gid.y), lutN<MAXG>(t, gid.z), lutN<MAXG>(t, gid.w));
+                const uint4 mm = make_uint4((ex.x ^ col.x) & vmask.x, (ex.y ^ col.y) & vmask.y, (ex.z ^ col.z) & vmask.z, (ex.w ^ col.w) & vmask.w);
+                const u64 B = ballot64(any4(mm));
+                if (!B) break;
+                if (k >= (u32)MAXG) return -1;
+                // the first row (in row order) that disagrees with its group's first row starts a new group: the rows of
+                // its old group that have its byte in this column
+                const int ld = __builtin_ctzll(B);
+                const uint4 nzm = make_uint4(bytes_ne_mask(mm.x, 0u), bytes_ne_mask(mm.y, 0u), bytes_ne_mask(mm.z, 0u), bytes_ne_mask(mm.w, 0u));
+                const u32 ix = (u32)__builtin_amdgcn_readlane((int)first_byte_index(nzm), ld);
+                const u32 gold = leader_byte(gid, ld, ix), bnew = leader_byte(col, ld, ix);
+                const uint4 e1 = bytes_eq_mask(gid, gold * 0x01010101u), e2 = bytes_eq_mask(col, bnew * 0x01010101u);
+                const uint4 em = make_uint4(e1.x & e2.x, e1.y & e2.y, e1.z & e2.z, e1.w & e2.w);
+                const uint32_t kk = k * 0x01010101u;
+                gid.x = (gid.x & ~em.x) | (em.x & kk); gid.y = (gid.y & ~em.y) | (em.y & kk);
+                gid.z = (gid.z & ~em.z) | (em.z & kk); gid.w = (gid.w & ~em.w) | (em.w & kk);
+                if (lane == k) rep_l = (u32)ld * 16u + ix;
+#pragma unroll
+                for (int i = 0; i < MAXG / 4; i++) if ((k >> 2) == (u32)i) t[i] |= bnew << ((k & 3u) * 8u);
+                k++;
+            }
+        }
+    }
+    // ---- raw groups in the order of their first rows; strings of their first rows: lane = column
+    u32 rank_l = 0;
+    for (u32 g = 0; g < k; g++) rank_l += (u32)__builtin_amdgcn_readlane((int)rep_l, (int)g) < rep_l ? 1u : 0u;
+    // cells of the first rows -> LDS (raw[r][column], r-th raw group in first-row order), eight rows' loads in flight
+    uint8_t* raw = strs + 4096;
+    for (u32 r0 = 0; r0 < k; r0 += 8) {
+        u32 chv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            chv[i] = 0;
+            if (r0 + i < k) {
+                const u32 gs = (u32)__builtin_ctzll(ballot64(lane < k && rank_l == r0 + i));
+                const u32 row = (u32)__builtin_amdgcn_readlane((int)rep_l, (int)gs);
+                if (lane < ncol) {
+                    chv[i] = cell_ptr(lane)[row];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (r0 + i < k) raw[(r0 + i) * 64u + lane] = (uint8_t)chv[i];   // (lanes >= ncol: 0)
+    }
+    u32 lut[MAXG / 4];                                  // raw group -> final group
+#pragma unroll
+    for (int i = 0; i < MAXG / 4; i++) lut[i] = 0;
+    u32 nroot = 0, sumlen = 0, root_len_l = 0, root_slot_l = 0, root_rep_l = 0;   // lane t: root t
+    for (u32 r = 0; r < k; r++) {
+        const u32 gs = (u32)__builtin_ctzll(ballot64(lane < k && rank_l == r));
+        const u32 row = (u32)__builtin_amdgcn_readlane((int)rep_l, (int)gs);
+        const u32 c = raw[r * 64u + lane];
+        const u64 nulb = ballot64(c == 0u);             // lanes >= ncol hold 0
+        if (ncol < 64u ? (nulb & ((1ull << ncol) - 1ull)) != 0 : nulb != 0) return 0;   // a NUL ends a row's string (:282): generic kernels
+        const bool valid = lane < ncol;
+        if (CHECK_NL && lane < ncol && c == '\n') saw_nl = 1;
+        const bool keep = valid && c != '-' && c != '\n';
+        const u64 nz = ballot64(keep);
+        const u32 len = (u32)__builtin_popcountll(nz);
+        if (keep) strs[r * 64u + mbcnt(nz)] = (uint8_t)c;
+        // the same string as an earlier root?
+        u32 fin = nroot;
+        for (u32 tt = 0; tt < nroot; tt++) {
+            if ((u32)__builtin_amdgcn_readlane((int)root_len_l, (int)tt) != len) continue;
+            const u32 sl = (u32)__builtin_amdgcn_readlane((int)root_slot_l, (int)tt);
+            const bool diff = lane < len && strs[r * 64u + lane] != strs[sl * 64u + lane];
+            if (!ballot64(diff)) { fin = tt; break; }
+        }
+        if (fin == nroot) {
+            if (lane == nroot) { root_len_l = len; root_slot_l = r; root_rep_l = row; }
+            nroot++; sumlen += len;
+        }
+        // lut[gs >> 2] |= fin << ...  (static indices only: registers)
+#pragma unroll
+        for (int i = 0; i < MAXG / 4; i++) if ((gs >> 2) == (u32)i) lut[i] |= fin << ((gs & 3u) * 8u);
+    }
+    G.gid = make_uint4(lutN<MAXG>(lut, gid.x) | ~vmask.x, lutN<MAXG>(lut, gid.y) | ~vmask.y, lutN<MAXG>(lut, gid.z) | ~vmask.z, lutN<MAXG>(lut, gid.w) | ~vmask.w);
+    G.k = nroot; G.sumlen = sumlen; G.rep = root_rep_l; G.len = root_len_l; G.key_lo = 0; G.key_hi = 0;
+    return 1;
+}
+
 // Group the rows of a fast segment (msa_transforms.cpp:262-293: distinct gap-stripped strings in
 // order of first appearance).  Returns false when the segment must take the generic path.
 //   one column : DNA table lookups, else exact SWAR byte compares.
@@ -1604,7 +1752,7 @@ __global__ void __launch_bounds__(256) k_work_scatter(FastParams p, const u64* _
 // instantiation, which needs twice the registers).  1 = grouped, 0 = generic kernels.
 template <bool CHECK_NL, bool HEAVY>
 __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmeta, const uint4& col0, u32 rb, u32 lane,
-                                          const uint4& vmask, FastGroups& G, u32& saw_nl)
+                                          const uint4& vmask, FastGroups& G, u32& saw_nl, uint8_t* strs /* HEAVY: 2 x 64 x 64 bytes of LDS */)
 {
     const u32 ncol = (u32)(cmeta >> 48) & 0xffu;
     uint4 rm = vmask;
@@ -1649,126 +1797,22 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
     };
 
     if (!HEAVY && ncol > 10u) return 2;
-    if (ncol <= 20u) {
+    if (ncol <= 10u) {
         auto load_col = [&](u32 c) -> uint4 { return load16u(col_ptr(c)); };
-        int r;
-        if constexpr (HEAVY) r = ncol <= 10u ? fast_group_dnakeys<1>(load_col, ncol, col0, lane, vmask, G)
-                                             : fast_group_dnakeys<2>(load_col, ncol, col0, lane, vmask, G);
-        else r = fast_group_dnakeys<1>(load_col, ncol, col0, lane, vmask, G);
+        const int r = fast_group_dnakeys<1>(load_col, ncol, col0, lane, vmask, G);
         if (r) return r > 0 ? 1 : 0;
-        if (!HEAVY) return 2;
-        G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);          // another alphabet: the signature path below
+        G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);          // another alphabet
         G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
     }
-
     if constexpr (HEAVY) {
-    // ---- phase A: raw signatures of the 16 rows of this lane: sig_j(row) = sum_c byte(row,c) * W_j(c)
-    // (gaps are 0 and contribute nothing; v_mad_u32_u24 is full rate).  Rows with equal normalised
-    // columns get equal signatures; a collision of different rows is caught by the comparison in phase B.
-    u32 h1[16], h2[16], h3[16];
-    u32 nul = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { h1[i] = 0; h2[i] = 0; h3[i] = 0; }
-    auto weight = [](u32 c, u32 j) -> u32 { return FAST_W.v[c * 3u + j]; };
-#define EDSX_H(I)                                                                                 \
-        {                                                                                         \
-            const u32 bch = byte_at<I>(cn);                                                       \
-            h1[I] += __umul24(bch, w1); h2[I] += __umul24(bch, w2); h3[I] += __umul24(bch, w3);   \
-        }
-    for (u32 c0 = 0; c0 < ncol; c0 += 4) {
-        uint4 cvs[4];                                  // four column loads in flight
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            cvs[j] = make_uint4(0, 0, 0, 0);
-            if (c0 + j < ncol) cvs[j] = (c0 + j == 0) ? col0 : load16u(col_ptr(c0 + j));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (c0 + j < ncol) {
-                nul |= any_nul(cvs[j], vmask) ? 1u : 0u;
-                const uint4 cn = normalise_col<CHECK_NL>(cvs[j], vmask, saw_nl);
-                const u32 w1 = weight(c0 + j, 0), w2 = weight(c0 + j, 1), w3 = weight(c0 + j, 2);
-                EDSX_H(0) EDSX_H(1) EDSX_H(2) EDSX_H(3) EDSX_H(4) EDSX_H(5) EDSX_H(6) EDSX_H(7)
-                EDSX_H(8) EDSX_H(9) EDSX_H(10) EDSX_H(11) EDSX_H(12) EDSX_H(13) EDSX_H(14) EDSX_H(15)
-            }
-        }
-    }
-#undef EDSX_H
-    if (ballot64(nul != 0)) return 0;                  // msa_transforms.cpp:282: left to the exact generic kernels
-#ifdef EDSX_TEST_WEAK_SIG
-    // test-only build: one bit of signature, so that different rows collide all the time and the
-    // byte-for-byte verification in phase B is what keeps the groups right
-#pragma unroll
-    for (int i = 0; i < 16; i++) { h1[i] &= 1u; h2[i] = 0; h3[i] = 0; }
-#endif
-    // ---- phase B: raw groups in order of first appearance; each is keyed by its first row's gap-stripped
-    // string (+ length), so that raw groups spelling the same string (same letters, other gap placement)
-    // fall together in fast_assign
-    while (first_remaining(rm, leader, i0)) {
-        u32 m1 = 0, m2 = 0, m3 = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            m1 = (i0 == (u32)i) ? h1[i] : m1; m2 = (i0 == (u32)i) ? h2[i] : m2; m3 = (i0 == (u32)i) ? h3[i] : m3;
-        }
-        const u32 r1 = (u32)__builtin_amdgcn_readlane((int)m1, leader), r2 = (u32)__builtin_amdgcn_readlane((int)m2, leader);
-        const u32 r3 = (u32)__builtin_amdgcn_readlane((int)m3, leader);
-        uint32_t e[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-            if (h1[i] == r1 && h2[i] == r2 && h3[i] == r3) e[i >> 2] |= 0xffu << ((i & 3) * 8);
-        const uint4 eq = make_uint4(e[0] & rm.x, e[1] & rm.y, e[2] & rm.z, e[3] & rm.w);
-        // The signature only proposes the group: every member is now compared with the leader byte for
-        // byte over all columns (gaps normalised as above).  A mismatch is a signature collision: the
-        // segment goes to the generic kernels, which compare rows exactly.
-        {
-            u32 mism = 0;
-            for (u32 c = 0; c < ncol; c++) {               // (one load at a time: this path is rare, registers are not)
-                u32 dummy = 0;
-                const uint4 cn = normalise_col<false>(c == 0 ? col0 : load16u(col_ptr(c)), vmask, dummy);
-                const u32 lb = leader_byte(cn, leader, i0) * 0x01010101u;
-                mism |= ((cn.x ^ lb) & eq.x) | ((cn.y ^ lb) & eq.y) | ((cn.z ^ lb) & eq.z) | ((cn.w ^ lb) & eq.w);
-            }
-            if (ballot64(mism != 0)) return 0;
-        }
-        // the representative's string: lane = column
-        const u32 rep_row = (u32)leader * 16u + i0;
-        u32 ch = 0;
-        if (lane < ncol) {
-            const u64 sl = scatter ? mv.slot(seg_a + lane) : slot0 + lane;
-            ch = mv.vc[sl * (u64)mv.Spad + rep_row];
-            if (ch == '-' || ch == '\n') ch = 0;
-        }
-        const u64 nzm = ballot64(ch != 0);
-        const u32 len = (u32)__builtin_popcountll(nzm);
-        const u32 pos = mbcnt(nzm);
-        // key: the first 12 letters verbatim (96 bits: exact for strings up to 12 letters), the
-        // letters behind them hashed on top; the length goes into the key separately
-        u32 t1 = 0, t2 = 0, t3 = 0;
-        if (ch && pos < 12u) {
-            const u32 v = ch << ((pos & 3u) * 8u), wsel = pos >> 2;
-            t1 = wsel == 0u ? v : 0u; t2 = wsel == 1u ? v : 0u; t3 = wsel == 2u ? v : 0u;
-        }
-        if (len > 12u) {                                   // wave-uniform
-            if (ch && pos >= 12u) {
-                u32 x = (ch + 1u) * 0x9e3779b1u ^ (pos + 1u) * 0x85ebca77u;
-                x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15;
-                t1 = x * 0x735a2d97u; t1 ^= t1 >> 15;
-                t2 = (x ^ 0x5bd1e995u) * 0xc2b2ae3du; t2 ^= t2 >> 13;
-                t3 = (x + 0x27d4eb2fu) * 0x165667b1u; t3 ^= t3 >> 16;
-            }
-        }
-        t1 = wave_xor_all(t1); t2 = wave_xor_all(t2); t3 = wave_xor_all(t3);
-#ifdef EDSX_TEST_WEAK_SIG
-        if (len > 12u) { t1 &= 1u; t2 = 0; t3 = 0; }
-#endif
-        const u64 klo = ((u64)t2 << 32) | t1, khi = ((u64)len << 32) | t3;
-        // Keys of up to 12 letters are the string itself.  Longer ones are hashed: an equal key then only
-        // SUGGESTS that two raw groups (same letters, other gap placement) spell one string, so such a
-        // segment is left to the exact generic kernels.
-        if (len > 12u && ballot64(lane < G.k && G.key_lo == klo && G.key_hi == khi)) return 0;
-        if (!fast_assign(G, rm, eq, klo, khi, len, lane, rep_row)) return 0;
-    }
-    return 1;
+        auto cell_ptr = [&](u32 c) -> const uint8_t* {     // column c, row 0
+            const uint8_t* cp = two ? (c < nA ? cbase + (u64)c * mv.Spad : cbaseB + (u64)(c - nA) * mv.Spad)
+                                    : (scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + loff : cbase + (u64)c * mv.Spad);
+            return cp - loff;
+        };
+        int r = refine_groups<16, CHECK_NL>(col_ptr, cell_ptr, ncol, col0, lane, vmask, G, saw_nl, strs);
+        if (r < 0) r = refine_groups<64, CHECK_NL>(col_ptr, cell_ptr, ncol, col0, lane, vmask, G, saw_nl, strs);   // (rare: 17..64 raw groups)
+        return r > 0 ? 1 : 0;
     } else return 2;
 }
 
@@ -1778,6 +1822,8 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
 template <bool HEAVY>
 __global__ void __launch_bounds__(256, HEAVY ? 2 : 4) k_seg_group(FastParams p)
 {
+    __shared__ uint8_t strs_all[HEAVY ? 4 * 8192 : 4];
+    uint8_t* strs = strs_all + (HEAVY ? (threadIdx.x >> 6) * 8192u : 0u);
     const MsaView& mv = p.mv;
     if (mv.hdr->status) return;
     const u32 lane = threadIdx.x & 63;
@@ -1810,7 +1856,7 @@ __global__ void __launch_bounds__(256, HEAVY ? 2 : 4) k_seg_group(FastParams p)
         const u64 cm_v = lcm[i2], vi_v = lvi[i2];             // scalar after the wait below
         const u32 ncol = (u32)(cmeta >> 48) & 0xffu;
         FastGroups G;
-        const int ok = fast_group<true, HEAVY>(mv, (cmeta & CNT_SCATTER) ? uniform64(p.seg_start[seg]) : 0, cmeta, col, rb, lane, vmask, G, saw_nl);
+        const int ok = fast_group<true, HEAVY>(mv, (cmeta & CNT_SCATTER) ? uniform64(p.seg_start[seg]) : 0, cmeta, col, rb, lane, vmask, G, saw_nl, strs);
         // wait for the prefetched column here, before this segment's stores are queued behind it
         // (vmcnt retires in issue order)
         asm volatile("" :: "v"(col_n.x), "v"(col_n.y), "v"(col_n.z), "v"(col_n.w), "v"(rb_n), "v"(cm_v), "v"(vi_v));
