@@ -444,6 +444,15 @@ __device__ __forceinline__ u32 wave_scan_incl(u32 v)
     v += dpp_move0<0x143, 0xc>(v);       // row_bcast:31 -> rows 2, 3
     return v;
 }
+// four independent inclusive prefix sums, step by step side by side (a DPP instruction needs two wait states behind the
+// write of its source: the other three scans fill them)
+__device__ __forceinline__ void wave_scan_incl4(u32& a, u32& b, u32& c, u32& d)
+{
+#define EDSX_STEP(CTRL, RM) { const u32 ta = dpp_move0<CTRL, RM>(a), tb = dpp_move0<CTRL, RM>(b), tc = dpp_move0<CTRL, RM>(c), td = dpp_move0<CTRL, RM>(d); \
+                              a += ta; b += tb; c += tc; d += td; }
+    EDSX_STEP(0x111, 0xf) EDSX_STEP(0x112, 0xf) EDSX_STEP(0x114, 0xf) EDSX_STEP(0x118, 0xf) EDSX_STEP(0x142, 0xa) EDSX_STEP(0x143, 0xc)
+#undef EDSX_STEP
+}
 // minimum of v over lanes 0..7 (wave-uniform)
 __device__ __forceinline__ u32 min_lanes8(u32 v)
 {
@@ -780,13 +789,12 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
         if (fused_tile) { if constexpr (HOLD && LANEROWS) {
             // ---- all variant columns of the tile -> LDS (column-major, natural row order)
             if (V16) {
-                u32 idx = pre_of(j);
+                // (threads whose 16 rows do not exist write into the 16 bytes of slack behind the column's rows)
+                uint8_t* dst = colbuf + (size_t)pre_of(j) * p.Spad + (sub * 16u < p.Spad - 16u ? sub * 16u : p.Spad - 16u);
 #define EDSX_L(I)                                                                                 \
                 if (V16 & (1u << I)) {                                                            \
-                    if (sub * 16u < p.S)                                                          \
-                        *reinterpret_cast<uint4*>(colbuf + (size_t)idx * p.Spad + sub * 16) =     \
-                            make_uint4(tr[I][0], tr[I][1], tr[I][2], tr[I][3]);                    \
-                    idx++;                                                                        \
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(tr[I][0], tr[I][1], tr[I][2], tr[I][3]); \
+                    dst += p.Spad;                                                                \
                 }
                 EDSX_L(0) EDSX_L(1) EDSX_L(2) EDSX_L(3) EDSX_L(4) EDSX_L(5) EDSX_L(6) EDSX_L(7)
                 EDSX_L(8) EDSX_L(9) EDSX_L(10) EDSX_L(11) EDSX_L(12) EDSX_L(13) EDSX_L(14) EDSX_L(15)
@@ -1517,6 +1525,7 @@ constexpr u32 REC_H_SLOT = 8, REC_H_REP = 16;
 __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
 {
     const MsaView& mv = p.mv;
+    if (mv.hdr->status) return;                           // vc overflow: slots past the capacity exist; the host grows vc and replans
     const u64 nseg = *p.nseg_ptr;
     const u64 p0 = mv.vbit(0) ? 0 : 1;                   // variant and common segments alternate
     if (blockIdx.x == 0 && threadIdx.x == 0) mv.hdr->nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
@@ -1569,6 +1578,7 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
 // the heavy grouping kernel's list: the items the light one flagged
 __global__ void __launch_bounds__(256) k_heavy_scatter(FastParams p, const u64* __restrict__ pos)
 {
+    if (p.mv.hdr->status) return;
     const u64 n = *p.cnt_n, tot = *p.heavy_n;
     for (u64 it = blockIdx.x * (u64)blockDim.x + threadIdx.x; it < n; it += (u64)gridDim.x * blockDim.x) {
         const u64 a = pos[it], b = it + 1 < n ? pos[it + 1] : tot;
@@ -1580,6 +1590,7 @@ __global__ void __launch_bounds__(256) k_heavy_scatter(FastParams p, const u64* 
 // flags (no atomics: 4 M appends to one counter would take milliseconds)
 __global__ void __launch_bounds__(256) k_work_scatter(FastParams p, const u64* __restrict__ pos, const u64* __restrict__ nvs_ptr)
 {
+    if (p.mv.hdr->status) return;
     const u64 nvs = *nvs_ptr;
     for (u64 vi = blockIdx.x * (u64)blockDim.x + threadIdx.x; vi < nvs; vi += (u64)gridDim.x * blockDim.x) {
         const u64 cm = p.cnt_meta[vi];
@@ -2140,15 +2151,16 @@ __device__ __forceinline__ void emit_ids2(u32 x0, u32 k, u32 S, u32 lane, const 
     const bool v0 = lane < S, v1 = lane + 64u < S, vt = C.tlt != 0;
     const u32 tl0 = lane < 9u ? 2u : 3u, tl1 = lane < 35u ? 3u : 4u;       // ids 1-9 | 10-64 and 65-99 | 100-128
     const u32 f0 = v0 ? tl0 << (g0 * 8u) : 0u, f1 = v1 ? tl1 << (g1 * 8u) : 0u, ft = C.tlt << (gt_ * 8u);
-    const u32 i0 = wave_scan_incl(f0), i1 = wave_scan_incl(f1), it = wave_scan_incl(ft);
-    const u32 ex0 = ((i0 - f0) >> (g0 * 8u)) & 0xffu, ex1 = ((i1 - f1) >> (g1 * 8u)) & 0xffu, ext = ((it - ft) >> (gt_ * 8u)) & 0xffu;
-    const u32 tot0 = (u32)__builtin_amdgcn_readlane((int)i0, 63), tot1 = (u32)__builtin_amdgcn_readlane((int)i1, 63);
-    const u32 tott = (u32)__builtin_amdgcn_readlane((int)it, 63);
     // ---- the whole lanes: ids of strings 0..2 in this lane (string 3 has the rest), prefix over the lanes
     const u32 lo = x0 & 0x55555555u, hi = (x0 >> 1) & 0x55555555u;
     const u32 c1 = (u32)__builtin_popcount(lo & ~hi), c2 = (u32)__builtin_popcount(hi & ~lo), c3 = (u32)__builtin_popcount(lo & hi);
     const u32 pk = ((16u - c1 - c2 - c3) | (c1 << 10) | (c2 << 20)) & C.bmask;
-    const u32 sp = wave_scan_incl(pk), ep = sp - pk;
+    u32 i0 = f0, i1 = f1, it = ft, sp = pk;
+    wave_scan_incl4(i0, i1, it, sp);
+    const u32 ex0 = ((i0 - f0) >> (g0 * 8u)) & 0xffu, ex1 = ((i1 - f1) >> (g1 * 8u)) & 0xffu, ext = ((it - ft) >> (gt_ * 8u)) & 0xffu;
+    const u32 tot0 = (u32)__builtin_amdgcn_readlane((int)i0, 63), tot1 = (u32)__builtin_amdgcn_readlane((int)i1, 63);
+    const u32 tott = (u32)__builtin_amdgcn_readlane((int)it, 63);
+    const u32 ep = sp - pk;
     const u32 totp = (u32)__builtin_amdgcn_readlane((int)sp, 63);
     const u32 pre0 = ep & 0x3ffu, pre1 = (ep >> 10) & 0x3ffu, pre2 = ep >> 20, pre3 = 16u * (lane - 8u) - pre0 - pre1 - pre2;
     const u32 t0 = totp & 0x3ffu, t1 = (totp >> 10) & 0x3ffu, t2 = totp >> 20, t3 = 16u * C.nbody - t0 - t1 - t2;
@@ -2156,12 +2168,19 @@ __device__ __forceinline__ void emit_ids2(u32 x0, u32 k, u32 S, u32 lane, const 
     const u32 sh8 = (lane & 3u) * 8u;
     const u32 hb = ((tot0 >> sh8) & 0xffu) + ((tot1 >> sh8) & 0xffu), tb_ = (tott >> sh8) & 0xffu;
     const u32 bb = 4u * (lane == 0u ? t0 : lane == 1u ? t1 : lane == 2u ? t2 : t3);
+    // The string's region in `stage` starts at a multiple of 16 and has `lead` bytes of padding in front, so that
+    // (P + 1 + hb) % 4 == 0: the 4-byte tokens are dword-aligned.  It is copied out as hn bytes up to the first 16-byte
+    // boundary, nfull aligned 16-byte chunks and tn bytes behind them.  One scan gives region, output offset and chunk index.
     const u32 sz = lane < k ? 1u + hb + bb + tb_ : 0u;           // '{' + tokens; the last ',' becomes '}'
-    const u32 rs = lane < k ? (sz + 6u) & ~3u : 0u;              // region: up to 3 bytes of padding in front
-    const u32 pq = rs | (sz << 16);
+    const u32 lead = (3u - hb) & 3u;
+    const u32 hn = lead ? (sz < 16u - lead ? sz : 16u - lead) : 0u;
+    const u32 nfull = (sz - hn) >> 4, tn = (sz - hn) & 15u;
+    const u32 rs = lane < k ? (lead + sz + 15u) >> 4 : 0u;       // region in units of 16 bytes
+    const u32 pq = rs | (sz << 9) | (nfull << 22);               // sums: <= 290 | <= 4125 | <= 260
     const u32 sq = wave_scan_incl(pq), eq_ = sq - pq;
-    const u32 P = (eq_ & 0xffffu) + ((3u - hb) & 3u);            // (P + 1 + hb) % 4 == 0: the 4-byte tokens are aligned
-    const u32 off = eq_ >> 16;
+    const u32 P = ((eq_ & 0x1ffu) << 4) + lead;
+    const u32 off = (eq_ >> 9) & 0x1fffu, cs = eq_ >> 22;
+    const u32 T = (u32)__builtin_amdgcn_readlane((int)sq, 63) >> 22;
     if (lane < k) { L.gt[lane] = sbase + P + 1u; L.gt[16 + lane] = sbase + P + 1u + hb; L.gt[32 + lane] = sbase + P + 1u + hb + bb; }
     // ---- cursors of the whole lanes (the other lanes: their dummy dword, advanced by 0)
     {
@@ -2209,11 +2228,6 @@ __device__ __forceinline__ void emit_ids2(u32 x0, u32 k, u32 S, u32 lane, const 
     // ---- copy the regions out.  String g: LDS [P, P + sz) -> gseds + off.  hn bytes up to the first 16-byte
     // boundary of the LDS image, nfull aligned 16-byte chunks, tn bytes behind them.
     pre_flush();                                                 // (the caller's wait for its prefetched loads)
-    const u32 lead = P & 15u;
-    const u32 hn = lead ? (sz < 16u - lead ? sz : 16u - lead) : 0u;
-    const u32 nfull = (sz - hn) >> 4, tn = (sz - hn) & 15u;
-    const u32 cinc = wave_scan_incl(nfull), cs = cinc - nfull;
-    const u32 T = (u32)__builtin_amdgcn_readlane((int)cinc, 63);
     const u32 cs1 = (u32)__builtin_amdgcn_readlane((int)cs, 1), cs2 = (u32)__builtin_amdgcn_readlane((int)cs, 2);
     const u32 cs3 = (u32)__builtin_amdgcn_readlane((int)cs, 3);           // (lanes >= k: no chunks, cs = T)
     if (lane < k) {
@@ -2608,11 +2622,7 @@ int MsaPipeline::get_timing(const char** names, float* ms, int* counts, int cap)
 
 #define TIMED(name, st, ...) do { launch_timer_begin(name, st); __VA_ARGS__; launch_timer_end(st); } while (0)
 
-MsaPipeline::~MsaPipeline()
-{
-    clear_timers();
-    if (side_) { (void)hipStreamDestroy(side_); (void)hipEventDestroy(ev_fork_); (void)hipEventDestroy(ev_join_); }
-}
+MsaPipeline::~MsaPipeline() { clear_timers(); }
 
 static const char* status_message(u64 st)
 {
@@ -2987,32 +2997,23 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_emit_variant),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     if (fast_) {
-        // The main emitter (segments of up to four strings) is bound by its stores; the common text, the wide and the
-        // generic emitters are small and latency-bound: they run beside it on a second stream.
-        if (!side_) {
-            EDSX_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
-            EDSX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-            EDSX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-        }
-        EDSX_HIP(hipEventRecord(ev_fork_, st));
-        EDSX_HIP(hipStreamWaitEvent(side_, ev_fork_, 0));
+        // (Running the common text, the wide and the generic emitters beside the main emitter on a second stream was
+        // measured: the persistent main emitter fills every CU, the side kernels only slow it down - 41.0 vs 39.7 ms.)
         FastParams fp = fp_;
         fp.eds = d_eds; fp.seds = d_seds;
         { const char* e = getenv("EDSX_DBG"); fp.dbg = e ? (u32)atoi(e) : 0u; }
-        auto launch_emit = [&](auto kern, const char* name, hipStream_t s) {
-            TIMED(name, s, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
-                                              dim3(256), 0, s, fp));
+        auto launch_emit = [&](auto kern, const char* name) {
+            TIMED(name, st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
+                                               dim3(256), 0, st, fp));
         };
-        launch_emit(k_emit_fast2, "k_emit_fast", st);
-        TIMED("k_emit_common", side_, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, side_, ep));
-        if (h_.S >= 1000) launch_emit(k_emit_fast<true, true>, "k_emit_fast_wide", side_);      // ids of five bytes exist
-        else launch_emit(k_emit_fast<false, true>, "k_emit_fast_wide", side_);
+        launch_emit(k_emit_fast2, "k_emit_fast");
+        TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
+        if (h_.S >= 1000) launch_emit(k_emit_fast<true, true>, "k_emit_fast_wide");      // ids of five bytes exist
+        else launch_emit(k_emit_fast<false, true>, "k_emit_fast_wide");
         ep.list = fp_.slow_list; ep.list_n = fp_.slow_count;
-        TIMED("k_emit_variant_slow", side_, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, side_, ep));
+        TIMED("k_emit_variant_slow", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
         ep.list = fp_.slow_list2; ep.list_n = fp_.slow_count2;
-        TIMED("k_emit_variant_slow2", side_, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, side_, ep));
-        EDSX_HIP(hipEventRecord(ev_join_, side_));
-        EDSX_HIP(hipStreamWaitEvent(st, ev_join_, 0));
+        TIMED("k_emit_variant_slow2", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
     } else {
         TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
         TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));

@@ -185,8 +185,6 @@ private:
     u32 recf_stride_ = 0, recf_gid_ = 0;
     FastParams fp_{};
     int cus_ = 0;
-    hipStream_t side_ = nullptr;            // common text, wide and generic emitters run beside the main emitter
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
 };
 
 } // namespace edsx

@@ -323,3 +323,25 @@ def test_full_size_config4_sampled_against_oracle(ctx):
     assert res["windows"] >= 32 and res["max_seds_offset_compared"] == Q and res["size_rule"] == "ok", res
     del buf, d_eds, d_seds
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("S,L,vf", [(50, 20000, 0.3), (300, 40000, 0.5), (1000, 20000, 0.9)])
+def test_dense_variant_columns_grow_the_column_store(ctx, S, L, vf):
+    """More variant columns than the first guess of the variant-column store holds (1/8 of the columns): the
+    plan overflows, the host grows the store and replans.  Every kernel of the first attempt must stay inside its
+    buffers (the slots past the capacity exist only as numbers)."""
+    import torch
+    import edsparser_amd
+    n = edsparser_amd.synth_size(S, L)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    fresh = edsparser_amd.Context(0)                       # a context whose buffers have not grown yet
+    fresh.msa_synth_device(buf.data_ptr(), n, S, L, variant_fraction=vf, seed=7)
+    E, Q = fresh.msa_plan_device(buf.data_ptr(), n, 0)
+    d_eds = torch.empty(E + 16, dtype=torch.uint8, device="cuda:0")
+    d_seds = torch.empty(Q + 16, dtype=torch.uint8, device="cuda:0")
+    fresh.msa_emit_device(d_eds.data_ptr(), d_seds.data_ptr())
+    torch.cuda.synchronize()
+    oe, os_ = o.msa(bytes(buf.cpu().numpy()), 0)
+    assert bytes(d_eds[:E].cpu().numpy()) == oe
+    assert bytes(d_seds[:Q].cpu().numpy()) == os_
+    fresh.close()
