@@ -1,12 +1,14 @@
 #!/bin/bash
-# rocprofv3 evidence for the default bench workload: kernel stats, then FETCH_SIZE and WRITE_SIZE in passes of their own
+# rocprofv3 evidence for the default bench workload: kernel stats, then FETCH_SIZE and WRITE_SIZE in passes of their own.
+# usage (on the GPU box): profiles/collect.sh <tag>      -> gpurun_out/prof_<tag>, pmc_<tag>_fetch, pmc_<tag>_write
 set -e
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_v5 -o v5 --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-baseline-mb 0 > $R/gpurun_out/prof_v5.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o $TAG --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-baseline-mb 0 --verify 0 > $R/gpurun_out/prof_$TAG.log 2>&1
 echo "stats rc=$?"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_v5_fetch -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline-mb 0 > $R/gpurun_out/pmc_v5_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${TAG}_fetch -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline-mb 0 --verify 0 > $R/gpurun_out/pmc_${TAG}_fetch.log 2>&1
 echo "fetch rc=$?"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_v5_write -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline-mb 0 > $R/gpurun_out/pmc_v5_write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${TAG}_write -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline-mb 0 --verify 0 > $R/gpurun_out/pmc_${TAG}_write.log 2>&1
 echo "write rc=$?"
-tail -1 $R/gpurun_out/prof_v5.log | cut -c1-300
+tail -1 $R/gpurun_out/prof_$TAG.log | cut -c1-300

@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 outputs of profiles/collect.sh (merged into gpurun_out/) into the tracked summaries:
-profiles/r01_<tag>_full_kernel_stats.csv, r01_<tag>_pmc_hbm.md, hbm_traffic.json.  Usage: summarise.py v4"""
+profiles/<tag>_full_kernel_stats.csv, <tag>_pmc_hbm.md, hbm_traffic.json.  Usage: summarise.py r02a"""
 import csv, collections, json, os, shutil, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go = os.path.join(root, "gpurun_out")
-shutil.copy(os.path.join(go, "prof_%s" % tag, "%s_kernel_stats.csv" % tag), os.path.join(root, "profiles", "r01_%s_full_kernel_stats.csv" % tag))
+shutil.copy(os.path.join(go, "prof_%s" % tag, "%s_kernel_stats.csv" % tag), os.path.join(root, "profiles", "%s_full_kernel_stats.csv" % tag))
 with open(os.path.join(go, "prof_%s.log" % tag)) as f:
     lines = [l for l in f if l.startswith('{"metric"')]
-open(os.path.join(root, "profiles", "r01_%s_full_bench_under_rocprof.json" % tag), "w").write(lines[-1])
-bj = os.path.join(go, "bench_r01_%s.json" % tag)
+open(os.path.join(root, "profiles", "%s_full_bench_under_rocprof.json" % tag), "w").write(lines[-1])
+bj = os.path.join(go, "bench_%s.json" % tag)
 if os.path.exists(bj):
-    shutil.copy(bj, os.path.join(root, "profiles", "r01_%s_full_bench.json" % tag))
+    shutil.copy(bj, os.path.join(root, "profiles", "%s_full_bench.json" % tag))
 
 def agg(path):
     acc = collections.defaultdict(float); n = collections.Counter(); seen = set()
@@ -24,7 +24,7 @@ def agg(path):
     return {k: acc[k] / n[k] for k in acc}
 f = agg(os.path.join(go, "pmc_%s_fetch" % tag, "p_counter_collection.csv"))
 w = agg(os.path.join(go, "pmc_%s_write" % tag, "p_counter_collection.csv"))
-out = ["# HBM traffic per launch from rocprofv3 PMC counters (round 1, build %s, 1000 x 100 Mb workload)" % tag, "",
+out = ["# HBM traffic per launch from rocprofv3 PMC counters (build %s, 1000 x 100 Mb workload)" % tag, "",
        "Collected in two separate passes (`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`,",
        "`python3 bench.py --steps 1 --warmup 1 --cpu-baseline-mb 0`, script `profiles/collect.sh`), averaged over the",
        "launches of each kernel.  FETCH_SIZE/WRITE_SIZE are reported in KB.  On gfx950 FETCH_SIZE counts a 128-B request",
@@ -41,7 +41,7 @@ for k in sorted(f, key=lambda k: -(f[k] + w.get(k, 0))):
     out.append("| %s | %.2f | %.2f | %.2f | %.2f |" % (k, fr, 2 * fr, wr, 2 * fr + wr))
     tj[k] = round((2 * f[k] + w.get(k, 0)) * 1024)
 out += ["", "k_scan_extract: algorithmic bytes = 1000 x 1e8 cells = 100.0 GB read once; the counters say %.1f GB read +" % (2 * f['k_scan_extract'] * 1024 / 1e9),
-        "%.1f GB written (the variant-column store vc: 11.78 M columns x 1040 B).  No re-reads." % (w['k_scan_extract'] * 1024 / 1e9)]
-open(os.path.join(root, "profiles", "r01_%s_pmc_hbm.md" % tag), "w").write("\n".join(out) + "\n")
-json.dump({"1000x100000000": dict(tj, source="profiles/r01_%s_pmc_hbm.md" % tag)}, open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1)
+        "%.1f GB written (grouping records of the runs the scan groups itself + the variant columns it hands on).  No re-reads." % (w['k_scan_extract'] * 1024 / 1e9)]
+open(os.path.join(root, "profiles", "%s_pmc_hbm.md" % tag), "w").write("\n".join(out) + "\n")
+json.dump({"1000x100000000": dict(tj, source="profiles/%s_pmc_hbm.md" % tag)}, open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1)
 print("\n".join(out))
