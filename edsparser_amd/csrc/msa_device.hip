@@ -267,6 +267,13 @@ __global__ void k_index_rows(const uint8_t* __restrict__ f, u64 n, MsaHdr* h,
     }
 }
 
+// rows S .. n-1 of the row-start table repeat row S-1: the column scan's threads load 16 consecutive row starts
+__global__ void k_pad_rows(u64* __restrict__ row_start, u64 S, u64 n)
+{
+    const u64 last = row_start[S - 1];
+    for (u64 r = S + blockIdx.x * (u64)blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) row_start[r] = last;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: column scan + variant-column extraction.  One workgroup owns a tile of W = 16*CPR raw
 // columns for ALL rows: T threads, thread (sub, j) holds the 16-byte chunk j of rows
@@ -634,11 +641,76 @@ __device__ __forceinline__ uint2 pack_gid4(const uint4& gid, const uint4& vmask)
     return make_uint2(p(gid.x & vmask.x) | (p(gid.y & vmask.y) << 16), p(gid.z & vmask.z) | (p(gid.w & vmask.w) << 16));
 }
 
+// One run of variant columns that lies inside a tile of the column scan, grouped by one wave from the LDS image of
+// the tile's variant columns (colbuf, column-major, natural row order): lane l = rows 16l .. 16l+15
+// (msa_transforms.cpp:262-293).  desc = index of the run's first column in colbuf | width << 11.  Writes the fused
+// record (group ids + .eds text) and rec_info, or - when the run is not for this path (another alphabet, more than
+// 16 strings, a long text) - copies its columns to vc for the grouping kernels.
+__device__ __forceinline__ void fused_group_run(const K1Params& p, const uint8_t* colbuf, u32 desc, u64 slot_base, u32 lane,
+                                                const uint4& vmask, u32 nl, u32 loff)
+{
+    const u32 idx0 = desc & 0x7ffu, w = desc >> 11;
+    const uint8_t* c0p = colbuf + (size_t)idx0 * p.Spad;
+    const uint4 col0 = *reinterpret_cast<const uint4*>(c0p + loff);
+    FastGroups G;
+    G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
+    G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
+    bool ok;
+    if (w == 1u) ok = fast_group_dna1(col0, lane < p.S ? (u32)c0p[lane] : 0u, vmask, lane, p.S, G);
+    else {
+        auto load_col = [&](u32 c) -> uint4 { return *reinterpret_cast<const uint4*>(c0p + (size_t)c * p.Spad + loff); };
+        ok = fast_group_dnakeys<1>(load_col, w, col0, lane, vmask, G) > 0;
+    }
+    const u32 textlen = 1u + G.k + G.sumlen;             // "{" + strings + separators / "}"
+    ok = ok && G.k <= 16u && textlen <= REC_TEXT_MAX;
+    const u64 slot = slot_base + idx0;
+    if (p.dbg & 64u) {
+        if (lane == 0 && !ok) p.rec_info[slot] = 0;
+    } else if (ok) {
+        uint8_t* rec = p.recf + slot * (u64)p.recf_stride;
+        if (lane < nl) {
+            if (G.k <= 4u) *reinterpret_cast<u32*>(rec + lane * 4u) = pack_gid2(G.gid, vmask);
+            else *reinterpret_cast<uint2*>(rec + lane * 8u) = pack_gid4(G.gid, vmask);
+        }
+        uint8_t* t = rec + p.recf_gid + 4;
+        if (w == 1u) {                             // lane g holds string g's letter (0: the empty string)
+            const u32 c = lane < G.k ? (u32)G.key_lo : 0u;
+            const u64 nz = ballot64(c != 0);
+            const u32 at = 1u + lane + mbcnt(nz);
+            if (lane < G.k) {
+                if (c) t[at] = (uint8_t)c;
+                t[at + (c ? 1u : 0u)] = lane + 1u < G.k ? ',' : '}';
+            }
+        } else {                                   // lane g holds string g as 3-bit classes
+            const u32 mine = lane < G.k ? G.len + 1u : 0u;
+            const u32 at = 1u + wave_scan_incl(mine) - mine;
+            const u32 sk = (u32)G.key_lo, sk2 = (u32)(G.key_lo >> 32);     // ten letters per dword
+            if (lane < G.k) {
+                for (u32 i = 0; i < G.len; i++)
+                    t[at + i] = (uint8_t)__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO,
+                                                               i < 10u ? (sk >> (3u * i)) & 7u : (sk2 >> (3u * (i - 10u))) & 7u);
+                t[at + G.len] = lane + 1u < G.k ? ',' : '}';
+            }
+        }
+        if (lane == 0) {
+            t[0] = '{';
+            *reinterpret_cast<u32*>(rec + p.recf_gid) = G.k | (textlen << 8);
+            p.rec_info[slot] = G.k | (textlen << 8) | (G.k > 4u ? 1u << 30 : 0u) | (1u << 31);
+        }
+    } else {                                       // not for this path: its columns go to vc after all
+        if (lane == 0) p.rec_info[slot] = 0;
+        for (u32 c = 0; c < w; c++)
+            for (u32 o = lane * 16u; o < p.Spad; o += 1024u)
+                *reinterpret_cast<uint4*>(p.vc + (slot + c) * (u64)p.Spad + o) =
+                    *reinterpret_cast<const uint4*>(c0p + (size_t)c * p.Spad + o);
+    }
+}
+
 template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW>
 __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t colbuf[];
-    __shared__ u32 D[256];
+    __shared__ __attribute__((aligned(16))) u32 D[256];
     __shared__ u32 pre[256];
     __shared__ u32 wtot[4];
     __shared__ u64 slot_base_sh;
@@ -672,11 +744,15 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     }
     // row starts -> LDS (the colbuf area is free until the extraction phase), so the data loads
     // below depend on fast ds_reads only and all RPT of them are in flight together
+    // (Full tiles of the lane-rows layout take their 16 consecutive row starts straight from the padded table -
+    // eight 16-byte loads that hit L1/L2 - so a wave issues its data loads without waiting for the workgroup.)
+    constexpr bool DIRECT_OK = HOLD && LANEROWS;
+    const bool direct = DIRECT_OK && full_tile && !(p.dbg & 8192u);      // workgroup-uniform
     u64* rs = reinterpret_cast<u64*>(colbuf);
-    for (u32 r = tid; r < p.S; r += T) rs[r] = p.row_start[r];
+    if (!direct) for (u32 r = tid; r < p.S; r += T) rs[r] = p.row_start[r];
     if (tid < 256) { D[tid] = 0; CS[tid] = 0; }
     if (tid == 0) { ncand_sh = 0; nst_sh = 0; }
-    __syncthreads();
+    if (!direct) __syncthreads();
 
     const uint8_t* f = p.file;
     const u32 Sm1 = p.S - 1;
@@ -689,7 +765,22 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     uint4 ref = make_uint4(0, 0, 0, 0);
     uint4 d[HOLD ? RPT : 1];
     uint4 acc = make_uint4(0, 0, 0, 0);                        // OR over rows of (row ^ ref): a byte is
-    if (full_tile) {                                           // non-zero iff some row differs there
+    if (direct) {
+        if constexpr (DIRECT_OK) {
+            ref = load16u(f + p.row_start[0] + q);
+            const ulonglong2* rp = reinterpret_cast<const ulonglong2*>(p.row_start + sub * 16u);   // padded: rows past S = row S-1
+            ulonglong2 rv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) rv[i] = rp[i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { d[2 * i] = load16u(f + rv[i].x + q); d[2 * i + 1] = load16u(f + rv[i].y + q); }
+#pragma unroll
+            for (int it = 0; it < RPT; it++) {
+                acc.x |= d[it].x ^ ref.x; acc.y |= d[it].y ^ ref.y;
+                acc.z |= d[it].z ^ ref.z; acc.w |= d[it].w ^ ref.w;
+            }
+        }
+    } else if (full_tile) {                                    // non-zero iff some row differs there
         ref = load16u(f + rs[0] + q);                          // fast path: unconditional 16-B loads
 #pragma unroll
         for (int it = 0; it < RPT; it++) {
@@ -736,26 +827,42 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
         for (int i = 0; i < nb; i++) { if (m == p.lw) { nlmask |= 1u << i; m = 0; } else m++; }
     }
     if ((chunk_eq16(ref, 0x0a0a0a0au) & valid) != nlmask) bad = 1;
-    if (diff) atomicOr(&D[j], diff);
+    if (direct) {
+        // OR over the lanes of the wave that hold the same chunk (lanes j, j + cpr, ..): one LDS atomic per wave and chunk
+        for (u32 o = cpr; o < 64u; o <<= 1) diff |= (u32)__shfl_xor((int)diff, (int)o, 64);
+        __syncthreads();                                       // D[] is zeroed (no barrier in front of the loads)
+        if ((tid & 63u) < cpr && diff) atomicOr(&D[j], diff);
+    } else if (diff) atomicOr(&D[j], diff);
     __syncthreads();
 
     const u32 V16 = D[j];
     if (V16 & nlmask) bad = 1;                                 // a row deviates at a newline slot
 
-    // exclusive prefix of popc(D[*]) over the tile's chunks (cpr <= 256 -> <= 4 waves)
-    if (tid < 256) {
-        u32 c = tid < cpr ? __builtin_popcount(D[tid]) : 0;
-        u32 incl = c;
-        for (int o = 1; o < 64; o <<= 1) { u32 a = __shfl_up(incl, o, 64); if ((tid & 63) >= (u32)o) incl += a; }
-        if ((tid & 63) == 63) wtot[tid >> 6] = incl;
-        pre[tid] = incl - c;
+    // exclusive prefix of popc(D[*]) over the tile's chunks
+    const bool fastpre = cpr <= 8u;                            // every thread derives it from the <= 8 masks itself
+    u64 prepk = 0;                                             // byte c: variant columns in chunks 0 .. c-1
+    u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0, nv = 0;
+    if (fastpre) {
+        const uint4 da = *reinterpret_cast<const uint4*>(&D[0]), db = *reinterpret_cast<const uint4*>(&D[4]);
+        const u32 dm[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+#pragma unroll
+        for (int c = 0; c < 8; c++) { prepk |= (u64)nv << (8 * c); nv += (u32)__builtin_popcount(dm[c]); }
+    } else {
+        if (tid < 256) {                                       // (cpr <= 256 -> <= 4 waves)
+            u32 c = tid < cpr ? __builtin_popcount(D[tid]) : 0;
+            u32 incl = c;
+            for (int o = 1; o < 64; o <<= 1) { u32 a = __shfl_up(incl, o, 64); if ((tid & 63) >= (u32)o) incl += a; }
+            if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+            pre[tid] = incl - c;
+        }
+        __syncthreads();
+        w0 = wtot[0]; w1 = wtot[1]; w2 = wtot[2]; w3 = wtot[3];
+        nv = w0 + w1 + w2 + w3;
     }
-    __syncthreads();
-    // every thread completes its own prefix (no third barrier); the slot atomic is issued now and its
-    // result is first needed after the extraction into LDS, which hides its ~1 us round trip
-    const u32 w0 = wtot[0], w1 = wtot[1], w2 = wtot[2], w3 = wtot[3];
-    const u32 nv = w0 + w1 + w2 + w3;
+    // (the slot atomic is issued now and its result is first needed after the extraction into LDS, which hides
+    // its ~1 us round trip)
     auto pre_of = [&](u32 chunk) -> u32 {
+        if (fastpre) return (u32)(prepk >> (8u * (chunk & 7u))) & 0xffu;
         const u32 cw = chunk >> 6;
         return pre[chunk] + (cw > 0 ? w0 : 0u) + (cw > 1 ? w1 : 0u) + (cw > 2 ? w2 : 0u);
     };
@@ -859,64 +966,8 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                 const u32 lane = tid & 63u, nl = (p.S + 15u) >> 4;
                 const uint4 vmask = fast_valid_mask(lane, p.S);
                 const u32 loff = lane * 16u < p.Spad - 16u ? lane * 16u : p.Spad - 16u;
-                for (u32 ci = uniform32(tid >> 6); ci < ncand; ci += T / 64) {
-                    const u32 desc = uniform32((u32)clist[ci]);
-                    const u32 idx0 = desc & 0x7ffu, w = desc >> 11;
-                    const uint8_t* c0p = colbuf + (size_t)idx0 * p.Spad;
-                    const uint4 col0 = *reinterpret_cast<const uint4*>(c0p + loff);
-                    FastGroups G;
-                    G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
-                    G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
-                    bool ok;
-                    if (w == 1u) ok = fast_group_dna1(col0, lane < p.S ? (u32)c0p[lane] : 0u, vmask, lane, p.S, G);
-                    else {
-                        auto load_col = [&](u32 c) -> uint4 { return *reinterpret_cast<const uint4*>(c0p + (size_t)c * p.Spad + loff); };
-                        ok = fast_group_dnakeys<1>(load_col, w, col0, lane, vmask, G) > 0;
-                    }
-                    const u32 textlen = 1u + G.k + G.sumlen;             // "{" + strings + separators / "}"
-                    ok = ok && G.k <= 16u && textlen <= REC_TEXT_MAX;
-                    const u64 slot = slot_base + idx0;
-                    if (p.dbg & 64u) {
-                        if (lane == 0 && !ok) p.rec_info[slot] = 0;
-                    } else if (ok) {
-                        uint8_t* rec = p.recf + slot * (u64)p.recf_stride;
-                        if (lane < nl) {
-                            if (G.k <= 4u) *reinterpret_cast<u32*>(rec + lane * 4u) = pack_gid2(G.gid, vmask);
-                            else *reinterpret_cast<uint2*>(rec + lane * 8u) = pack_gid4(G.gid, vmask);
-                        }
-                        uint8_t* t = rec + p.recf_gid + 4;
-                        if (w == 1u) {                             // lane g holds string g's letter (0: the empty string)
-                            const u32 c = lane < G.k ? (u32)G.key_lo : 0u;
-                            const u64 nz = ballot64(c != 0);
-                            const u32 at = 1u + lane + mbcnt(nz);
-                            if (lane < G.k) {
-                                if (c) t[at] = (uint8_t)c;
-                                t[at + (c ? 1u : 0u)] = lane + 1u < G.k ? ',' : '}';
-                            }
-                        } else {                                   // lane g holds string g as 3-bit classes
-                            const u32 mine = lane < G.k ? G.len + 1u : 0u;
-                            const u32 at = 1u + wave_scan_incl(mine) - mine;
-                            const u32 sk = (u32)G.key_lo, sk2 = (u32)(G.key_lo >> 32);     // ten letters per dword
-                            if (lane < G.k) {
-                                for (u32 i = 0; i < G.len; i++)
-                                    t[at + i] = (uint8_t)__builtin_amdgcn_perm(DNA_LET_HI, DNA_LET_LO,
-                                                                               i < 10u ? (sk >> (3u * i)) & 7u : (sk2 >> (3u * (i - 10u))) & 7u);
-                                t[at + G.len] = lane + 1u < G.k ? ',' : '}';
-                            }
-                        }
-                        if (lane == 0) {
-                            t[0] = '{';
-                            *reinterpret_cast<u32*>(rec + p.recf_gid) = G.k | (textlen << 8);
-                            p.rec_info[slot] = G.k | (textlen << 8) | (G.k > 4u ? 1u << 30 : 0u) | (1u << 31);
-                        }
-                    } else {                                       // not for this path: its columns go to vc after all
-                        if (lane == 0) p.rec_info[slot] = 0;
-                        for (u32 c = 0; c < w; c++)
-                            for (u32 o = lane * 16u; o < p.Spad; o += 1024u)
-                                *reinterpret_cast<uint4*>(p.vc + (slot + c) * (u64)p.Spad + o) =
-                                    *reinterpret_cast<const uint4*>(c0p + (size_t)c * p.Spad + o);
-                    }
-                }
+                for (u32 ci = uniform32(tid >> 6); ci < ncand; ci += T / 64)
+                    fused_group_run(p, colbuf, uniform32((u32)clist[ci]), slot_base, lane, vmask, nl, loff);
             }
         } } else
         for (u32 b0 = 0; b0 < nv || b0 == 0; b0 += cap) {
@@ -1816,6 +1867,13 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
         G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
     }
     if constexpr (HEAVY) {
+        if (ncol > 10u && ncol <= 20u) {                   // 11..20 columns over the DNA alphabet: exact keys in two dwords
+            auto load_col = [&](u32 c) -> uint4 { return load16u(col_ptr(c)); };
+            const int r = fast_group_dnakeys<2>(load_col, ncol, col0, lane, vmask, G);
+            if (r) return r > 0 ? 1 : 0;
+            G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);          // another alphabet
+            G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
+        }
         auto cell_ptr = [&](u32 c) -> const uint8_t* {     // column c, row 0
             const uint8_t* cp = two ? (c < nA ? cbase + (u64)c * mv.Spad : cbaseB + (u64)(c - nA) * mv.Spad)
                                     : (scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + loff : cbase + (u64)c * mv.Spad);
@@ -2670,6 +2728,10 @@ void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t s
     EDSX_HIP(hipStreamSynchronize(st));
     if (h_.status) throw FormatError(status_message(h_.status));
     if (h_.S > MAX_ROWS) throw FormatError(status_message(ST_TOO_MANY_ROWS));
+    {   // padding for the column scan's 16-row loads (at most 256 threads x 16 rows past the last one)
+        const u64 padded = std::min<u64>(ROW_CAP, (h_.S + 15) / 16 * 16 + 4096);
+        hipLaunchKernelGGL(k_pad_rows, dim3(4), dim3(256), 0, st, rows_.as<u64>(), h_.S, padded);
+    }
 
     const u64 Draw = h_.Draw;
     const u32 Spad = vc_pitch((u32)h_.S);

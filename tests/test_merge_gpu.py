@@ -57,6 +57,33 @@ def test_generated_reference_fixtures(ctx):
         assert got == c["expect"], c
 
 
+def _matches(packed, b):
+    import hashlib
+    if "text" in packed:
+        return packed["text"].encode() == b
+    return packed["len"] == len(b) and packed["sha256"] == hashlib.sha256(b).hexdigest()
+
+
+def test_generated_reference_fixtures_round2(ctx):
+    """500..2000 symbols, 8 merge rounds, LINEAR and CARTESIAN (tests/golden/make_golden2.py ran the reference)."""
+    for c in json.load(open(os.path.join(GOLDEN, "gen2_merge.json")))["cases"]:
+        out, so = ctx.leds_merge(c["eds"].encode(), c["seds"].encode() if c["seds"] is not None else None, c["l"], c["compact"])
+        assert _matches(c["expect"]["out"], out) and _matches(c["expect"]["seds_out"], so), c["name"]
+
+
+def test_baseline_config0_shape(ctx):
+    """BASELINE configs[0]: genrandomeds @5 % -> eds2leds -l 10 (CARTESIAN, compact), 0.2 MB reference, 28 MB out;
+    expected bytes = the reference's (length + SHA-256 in the fixture)."""
+    import hashlib
+    from merge_cases import genrandomeds_shaped
+    c0 = json.load(open(os.path.join(GOLDEN, "gen2_merge.json")))["configs0"]
+    g = c0["generator"]
+    eds, _ = genrandomeds_shaped(g["ref_mb"], g["v"], g["seed"])
+    assert len(eds) == c0["eds_len"] and hashlib.sha256(eds).hexdigest() == c0["eds_sha256"]
+    out, so = ctx.leds_merge(eds, None, c0["l"], c0["compact"])
+    assert _matches(c0["expect"]["out"], out) and _matches(c0["expect"]["seds_out"], so)
+
+
 def test_l0_is_invalid_argument(ctx):
     got = _run(ctx, b"{A}", None, 0)
     assert got["code"] == 3

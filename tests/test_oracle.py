@@ -117,3 +117,51 @@ def test_generated_goldens_still_match_reference():
     r = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), "--check"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- round-2 fixtures (tests/golden/make_golden2.py): equal-POS VCFs of 17..200 records, quirk 22-27 shapes, merges of
+# 500..2000 symbols with 8 rounds (LINEAR with 1 and 3 threads, CARTESIAN), BASELINE configs[0]'s shape at 0.2 MB
+def _matches(packed, b):
+    import hashlib
+    if "text" in packed:
+        return packed["text"].encode() == b
+    return packed["len"] == len(b) and packed["sha256"] == hashlib.sha256(b).hexdigest()
+
+
+def test_vcf_generated_goldens_round2():
+    cases = _load("gen2_vcf.json")["cases"]
+    assert sum(c["name"].startswith("samepos") for c in cases) >= 60
+    for c in cases:
+        e, s, st = o.vcf(c["vcf"].encode(), c["fasta"].encode(), c["l"])
+        assert {"eds": e.decode(), "seds": s.decode(), "stats": st} == c["expect"], c["name"]
+
+
+def test_merge_generated_goldens_round2():
+    doc = _load("gen2_merge.json")
+    for c in doc["cases"]:
+        assert c["rounds"] >= 6
+        out, so = o.merge(c["eds"].encode(), c["seds"].encode() if c["seds"] is not None else None, c["l"], c["compact"])
+        assert _matches(c["expect"]["out"], out) and _matches(c["expect"]["seds_out"], so), c["name"]
+        if "expect_threads3" in c:
+            assert c["expect_threads3"] == c["expect"], c["name"]
+
+
+def test_merge_baseline_config0_shape():
+    """BASELINE configs[0]: genrandomeds @5 % -> eds2leds -l 10 (CARTESIAN, compact) on a 0.2 MB reference."""
+    import hashlib
+    from merge_cases import genrandomeds_shaped
+    c0 = _load("gen2_merge.json")["configs0"]
+    g = c0["generator"]
+    eds, _ = genrandomeds_shaped(g["ref_mb"], g["v"], g["seed"])
+    assert len(eds) == c0["eds_len"] and hashlib.sha256(eds).hexdigest() == c0["eds_sha256"]
+    out, so = o.merge(eds, None, c0["l"], c0["compact"])
+    assert _matches(c0["expect"]["out"], out) and _matches(c0["expect"]["seds_out"], so)
+
+
+@pytest.mark.skipif(not o.have_ref(), reason="oracle/_ref not built (reference absent on this box)")
+def test_generated_goldens_round2_still_match_reference():
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden2.py"), "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

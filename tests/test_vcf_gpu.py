@@ -52,6 +52,15 @@ def test_generated_reference_fixtures(ctx):
         assert got == c["expect"], c
 
 
+def test_generated_reference_fixtures_round2(ctx):
+    """17..200 records with many equal POS (the reference's unstable std::sort decides their order, quirk 29) and the
+    SURVEY quirk 22-27 shapes; expected text from the reference itself (tests/golden/make_golden2.py)."""
+    cases = json.load(open(os.path.join(GOLDEN, "gen2_vcf.json")))["cases"]
+    for c in cases:
+        got = _run(ctx, c["vcf"].encode(), c["fasta"].encode(), c["l"])
+        assert got == c["expect"], c["name"]
+
+
 def _random_vcf(rng, L, nvar, ns, lw):
     ref = "".join(rng.choice("ACGT") for _ in range(L))
     fasta = ">chr1 synthetic\n" + "\n".join(ref[i:i + lw] for i in range(0, L, lw)) + "\n"
