@@ -9,8 +9,10 @@ A "step" is one full pass of the hot path (edsx_msa_plan_device + edsx_msa_emit_
 column scan + variant-column extraction, segment table, per-segment grouping, scans, .eds/.seds
 text) over one synthetic alignment that is already resident in HBM.  Workload at N=1: BASELINE
 configs[4], 1000 sequences x 100 Mb (genrandomeds-shaped, 5 % variant sites, one line per row).
-With N ranks the alignment is N x 100 Mb columns, range-partitioned by columns (weak scaling):
-every rank transforms its own slab and the boundary segments are stitched over RCCL.
+With N ranks (--scaling strong, the default: BASELINE configs[4] is ONE alignment over 1/2/4/8 GPUs) the same
+1000 x 100 Mb alignment is range-partitioned into N column slabs of 100/N Mb; every rank transforms its own slab
+and the boundary segments are stitched over RCCL inside the step (fixed-size tensor collectives).
+--scaling weak keeps 100 Mb columns per rank (an N x 100 Mb alignment).
 """
 import argparse
 import json
@@ -30,7 +32,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rows", type=int, default=1000)
-    ap.add_argument("--cols", type=int, default=100_000_000, help="alignment columns per GPU")
+    ap.add_argument("--cols", type=int, default=100_000_000,
+                    help="alignment columns (strong scaling: of the whole alignment; weak: per GPU)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: one alignment of --cols columns split into N column slabs; weak: --cols columns per rank")
     ap.add_argument("--context-len", type=int, default=0)
     ap.add_argument("--variant-fraction", type=float, default=0.05)
     ap.add_argument("--seed", type=int, default=42)
@@ -92,10 +97,15 @@ def main():
             dist.init_process_group(a.backend)
 
     ctx = edsparser_amd.Context(local_rank)
-    S, L, l = a.rows, a.cols, a.context_len
+    S, l = a.rows, a.context_len
+    if a.scaling == "strong":                                  # this rank's column slab of the one alignment
+        col0, col1 = a.cols * rank // world, a.cols * (rank + 1) // world
+    else:
+        col0, col1 = a.cols * rank, a.cols * (rank + 1)
+    L = col1 - col0
     n = edsparser_amd.synth_size(S, L)
     msa = torch.empty(n, dtype=torch.uint8, device="cuda")
-    ctx.msa_synth_device(msa.data_ptr(), n, S, L, col0=rank * L, variant_fraction=a.variant_fraction,
+    ctx.msa_synth_device(msa.data_ptr(), n, S, L, col0=col0, variant_fraction=a.variant_fraction,
                          seed=a.seed)
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
@@ -137,14 +147,19 @@ def main():
     dt = time.perf_counter() - t0
     timing = ctx.get_timing()
     ctx.set_timing(False)
+    n_total = float(n)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        dev = "cuda" if a.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        t = torch.tensor([float(n), float(out["E"]), float(out["Q"])], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)              # input bytes of all slabs (and the slabs' own text sizes)
+        n_total = float(t[0].item())
 
     info = ctx.msa_info()
     if rank == 0:
-        total_in = float(n) * world * a.steps
+        total_in = n_total * a.steps
         value = total_in / dt / 1e6
         dom = max(timing, key=lambda t: t[1]) if timing else None
         roof = None
@@ -187,16 +202,20 @@ def main():
         line = {
             "metric": "msa2eds_input_MB_per_s", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "msa2eds %d-seq x %d-column synthetic alignment per GPU "
+            "config": {"workload": "msa2eds %d-seq x %d-column synthetic alignment%s "
                                    "(genrandomeds-shaped, %.0f%% sites, one line per row)"
-                                   % (S, L, a.variant_fraction * 100),
-                       "rows": S, "cols_per_gpu": L, "context_len": l,
+                                   % (S, a.cols if a.scaling == "strong" else a.cols * world,
+                                      "" if world == 1 else " in %d column slabs of %d columns" % (world, L),
+                                      a.variant_fraction * 100),
+                       "rows": S, "cols_total": a.cols if a.scaling == "strong" else a.cols * world, "cols_per_gpu": L,
+                       "context_len": l,
                        "input_bytes_per_gpu": n, "eds_bytes": out["E"], "seds_bytes": out["Q"],
                        "segments": info["n_segments"], "variant_cols": info["n_variant_cols"],
                        "slow_segments": info["n_slow_segments"],
-                       "partition": "columns x %d" % world},
+                       "partition": "columns x %d" % world,
+                       "stitch": (out.get("stitch") or {}).get("chains") if world > 1 else None},
             "frac_of_hbm_read_roofline": round(value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4),
             "roofline": roof, "cpu_baseline": cpu, "verify": verify, "kernel_ms": per_kernel,
         }

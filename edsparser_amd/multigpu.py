@@ -124,43 +124,88 @@ def piece_bounds(edges, action):
     return e_lo, e_hi, s_lo, s_hi
 
 
-class SlabStitcher:
-    """Runs the stitch for one rank.  `dist` is torch.distributed (nccl = RCCL on the GPU box,
-    gloo in the CPU tests); only all_gather_object on small Python objects is used."""
+EDGE_FIELDS = ("n_segments", "cols", "eds_bytes", "seds_bytes", "first_is_variant", "first_cols", "first_eds_bytes",
+               "first_seds_bytes", "last_is_variant", "last_cols", "last_eds_bytes", "last_seds_bytes")
 
-    def __init__(self, rank, world, n_rows, dist, transform, get_edges, get_columns):
+
+class SlabStitcher:
+    """Runs the stitch for one rank.  `dist` is torch.distributed (nccl = RCCL on the GPU box, gloo in the CPU
+    tests).  Every exchange is a fixed-size tensor collective, the same calls on both backends:
+      1. all_gather of the edge descriptors, 12 int64 per rank;
+      2. only if a variant run crosses a boundary: all_gather of one uint8 buffer per rank with the raw columns of the
+         (at most two) variant chains the rank takes part in - every rank derives all block sizes from step 1, so the
+         buffers are padded to the largest contribution and need no size exchange;
+      3. only then: all_gather of the piece sizes, 2 int64 per rank (without a recomputed segment every rank derives all
+         sizes from step 1).
+    `device` is where the collective's tensors live ("cuda" for nccl, "cpu" for gloo)."""
+
+    def __init__(self, rank, world, n_rows, dist, transform, get_edges, get_columns, device=None):
         self.rank, self.world, self.n_rows, self.dist = rank, world, n_rows, dist
         self.transform = transform          # bytes (mini MSA) -> (eds, seds)
         self.get_edges = get_edges          # () -> SlabEdges of this rank's slab
         self.get_columns = get_columns      # (col0, ncols) -> row-major bytes of this rank's slab
+        self.device = device
         self.last = None
 
+    def _device(self):
+        if self.device is None:
+            self.device = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        return self.device
+
+    def _all_gather(self, t):
+        """t: 1-D tensor of the same length on every rank -> [world, len] (host copy)."""
+        import torch
+        out = torch.empty((self.world, t.numel()), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out.view(-1), t.contiguous())
+        return out.cpu()
+
     def stitch(self):
+        import torch
+        dev = self._device()
         my = self.get_edges()
-        gathered = [None] * self.world
-        self.dist.all_gather_object(gathered, my)
+        g = self._all_gather(torch.tensor([getattr(my, f) for f in EDGE_FIELDS], dtype=torch.int64, device=dev))
+        gathered = [SlabEdges(*[int(v) for v in g[r].tolist()]) for r in range(self.world)]
         plan = plan_stitch(gathered)
         action = plan.actions[self.rank]
-        if any(ch.variant for ch in plan.chains):
-            # raw columns of every variant chain this rank takes part in (KBs)
-            mine = {}
-            for ci, ch in enumerate(plan.chains):
-                if ch.variant:
-                    rng = chain_columns(ch, self.rank, gathered)
+        variant = [ci for ci, ch in enumerate(plan.chains) if ch.variant]
+        if variant:
+            # raw columns of the variant chains: rank r's buffer = its blocks in chain order, n_rows x ncols bytes each
+            def blocks_of(r):
+                out = []
+                for ci in variant:
+                    rng = chain_columns(plan.chains[ci], r, gathered)
                     if rng is not None:
-                        mine[ci] = (self.get_columns(rng[0], rng[1]), rng[1])
-            allcols = [None] * self.world
-            self.dist.all_gather_object(allcols, mine)
+                        out.append((ci, rng[0], rng[1]))
+                return out
+            sizes_r = [sum(self.n_rows * nc for _, _, nc in blocks_of(r)) for r in range(self.world)]
+            cap = max(max(sizes_r), 1)
+            buf = torch.zeros(cap, dtype=torch.uint8)
+            at = 0
+            for _ci, c0, nc in blocks_of(self.rank):
+                data = self.get_columns(c0, nc)
+                buf[at:at + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+                at += len(data)
+            allbuf = self._all_gather(buf.to(dev))
+            where = {}                                         # (rank, chain) -> (offset, ncols)
+            for r in range(self.world):
+                at = 0
+                for ci, _c0, nc in blocks_of(r):
+                    where[(r, ci)] = (at, nc)
+                    at += self.n_rows * nc
             for ci in action.owns:
                 ch = plan.chains[ci]
-                blocks = [allcols[r][ci] for r in range(ch.first, ch.last + 1)]
+                blocks = []
+                for r in range(ch.first, ch.last + 1):
+                    at, nc = where[(r, ci)]
+                    blocks.append((bytes(allbuf[r, at:at + self.n_rows * nc].numpy().tobytes()), nc))
                 e, s = self.transform(mini_alignment(blocks, self.n_rows))
                 action.extra_eds += e
                 action.extra_seds += s
         e_lo, e_hi, s_lo, s_hi = piece_bounds(my, action)
-        if any(ch.variant for ch in plan.chains):
-            sizes = [None] * self.world
-            self.dist.all_gather_object(sizes, ((e_hi - e_lo) + len(action.extra_eds), (s_hi - s_lo) + len(action.extra_seds)))
+        if variant:
+            sz = self._all_gather(torch.tensor([(e_hi - e_lo) + len(action.extra_eds), (s_hi - s_lo) + len(action.extra_seds)],
+                                               dtype=torch.int64, device=dev))
+            sizes = [(int(sz[r, 0]), int(sz[r, 1])) for r in range(self.world)]
         else:
             # no recomputed segment anywhere: every rank derives all piece sizes from the gathered edges
             sizes = []
@@ -184,7 +229,7 @@ def stitched_piece(eds, seds, result):
     return eds[e_lo:e_hi] + a.extra_eds, seds[s_lo:s_hi] + a.extra_seds
 
 
-def gpu_stitcher(ctx, mini_ctx, rank, world, n_rows, cols, dist):
+def gpu_stitcher(ctx, mini_ctx, rank, world, n_rows, cols, dist, device=None):
     """SlabStitcher wired to the C ABI: edges and columns from the planned slab in `ctx`, mini
     alignments through a second context so that the slab's plan stays intact."""
     def get_edges():
@@ -197,9 +242,121 @@ def gpu_stitcher(ctx, mini_ctx, rank, world, n_rows, cols, dist):
                          last_eds_bytes=e["last_eds_bytes"], last_seds_bytes=e["last_seds_bytes"]) if info else None
     get_edges.sizes = (0, 0)
     st = SlabStitcher(rank, world, n_rows, dist, lambda m: mini_ctx.msa_transform(m, 0), get_edges,
-                      lambda c0, nc: ctx.msa_copy_columns(c0, nc, n_rows))
+                      lambda c0, nc: ctx.msa_copy_columns(c0, nc, n_rows), device=device)
     st.set_sizes = lambda E, Q: setattr(get_edges, "sizes", (E, Q))
     return st
+
+
+# ------------------------------------------------------------------------------------------------------
+# msa2eds for a FILE over several GPUs: every rank cuts its column slab out of every row of the (memory-mapped)
+# alignment - column c of row s lives at start[s] + c + c / line_width (msa_transforms.cpp:268-269) -, hands
+# it to its GPU as a one-line-per-row image and the slabs are stitched as above.
+# ------------------------------------------------------------------------------------------------------
+def msa_layout(msa):
+    """Row starts and geometry of a FASTA alignment image (bytes-like with find): (starts, raw_row_bytes,
+    line_width or 0 for one-line rows, columns), or None when the file is not a plain uniform alignment (the
+    unpartitioned transform then reports what is wrong with it, in the reference's words)."""
+    n = len(msa)
+    if n == 0 or msa[0:1] != b">":
+        return None
+    he = msa.find(b"\n")
+    if he < 0:
+        return None
+    start0 = he + 1
+    h2 = msa.find(b"\n>", start0)
+    first_nl = msa.find(b"\n", start0)
+    if h2 < 0 or first_nl < 0:
+        return None
+    lw, draw = first_nl - start0, h2 - start0
+    if lw <= 0:
+        return None
+    if draw == lw:
+        L, wrapped = lw, False
+    else:
+        nlines = (draw + 1 + lw) // (lw + 1)
+        L, wrapped = draw + 1 - nlines, True
+        if L <= 0 or (L - 1) // lw != nlines - 1:
+            return None
+    starts, pos = [start0], h2 + 1
+    while pos < n:
+        if msa[pos:pos + 1] != b">":
+            if msa[pos:n].strip(b"\n"):
+                return None                                    # something else than blank lines behind the last row
+            break
+        he = msa.find(b"\n", pos)
+        if he < 0 or he + 1 + draw > n:
+            return None
+        st = he + 1
+        if st + draw < n and msa[st + draw:st + draw + 1] != b"\n":
+            return None
+        starts.append(st)
+        pos = st + draw + 1
+    if len(starts) < 2:
+        return None
+    return starts, draw, (lw if wrapped else 0), L
+
+
+def msa_slab_image(msa, layout, c0, c1):
+    """Columns [c0, c1) of every row as a one-line-per-row alignment image."""
+    starts, _draw, lw, _L = layout
+    out = bytearray()
+    for st in starts:
+        if lw:
+            piece = bytes(msa[st + c0 + c0 // lw:st + (c1 - 1) + (c1 - 1) // lw + 1]).replace(b"\n", b"")
+        else:
+            piece = bytes(msa[st + c0:st + c1])
+        out += b">r\n"
+        out += piece
+        out += b"\n"
+    return bytes(out)
+
+
+class MsaSharder:
+    """Column-slab partition of an alignment FILE for one rank (context length 0).  slab_fn(image, n_rows, ncols) ->
+    (eds, seds, SlabEdges, get_columns) transforms a slab (the C ABI on the GPU, the oracle in the CPU tests);
+    mini_fn(image) -> (eds, seds) transforms the few boundary columns of a variant run that crosses a cut."""
+
+    def __init__(self, rank, world, dist, slab_fn, mini_fn, whole_fn, device=None):
+        self.rank, self.world, self.dist = rank, world, dist
+        self.slab_fn, self.mini_fn, self.whole_fn, self.device = slab_fn, mini_fn, whole_fn, device
+
+    def run(self, msa, context_len=0):
+        rank, world = self.rank, self.world
+        layout = msa_layout(msa) if context_len == 0 else None
+        if layout is None or layout[3] < 2 * world or world == 1:
+            # not partitioned (l-EDS boundaries look across runs, msa_transforms.cpp:133-190; odd files): rank 0 alone
+            eds, seds = self.whole_fn(bytes(msa), context_len) if rank == 0 else (b"", b"")
+            import torch
+            dev = self.device or ("cuda" if self.dist.get_backend() == "nccl" else "cpu")
+            t = torch.tensor([len(eds), len(seds)], dtype=torch.int64, device=dev)
+            self.dist.broadcast(t, 0)
+            tot = [int(x) for x in t.cpu().tolist()]
+            return {"eds": eds, "seds": seds, "eds_offset": 0, "seds_offset": 0, "eds_total": tot[0], "seds_total": tot[1],
+                    "partitioned": False}
+        starts, _draw, _lw, L = layout
+        c0, c1 = L * rank // world, L * (rank + 1) // world
+        eds, seds, edges, get_columns = self.slab_fn(msa_slab_image(msa, layout, c0, c1), len(starts), c1 - c0)
+        st = SlabStitcher(rank, world, len(starts), self.dist, self.mini_fn, lambda: edges, get_columns, device=self.device)
+        res = st.stitch()
+        e, s = stitched_piece(eds, seds, res)
+        return {"eds": e, "seds": s, "eds_offset": res["eds_offset"], "seds_offset": res["seds_offset"],
+                "eds_total": res["eds_total"], "seds_total": res["seds_total"], "partitioned": True}
+
+
+def gpu_msa_sharder(ctx, mini_ctx, rank, world, dist, device=None):
+    """MsaSharder wired to the C ABI (host-buffer transform of the slab image; edges and boundary columns from the
+    slab's plan, mini alignments through a second context)."""
+    def slab_fn(image, n_rows, ncols):
+        eds, seds = ctx.msa_transform(image, 0)
+        e = ctx.msa_edge_info()
+        edges = SlabEdges(n_segments=e["n_segments"], cols=ncols, eds_bytes=len(eds), seds_bytes=len(seds),
+                          first_is_variant=e["first_is_variant"], first_cols=e["first_cols"],
+                          first_eds_bytes=e["first_eds_bytes"], first_seds_bytes=e["first_seds_bytes"],
+                          last_is_variant=e["last_is_variant"], last_cols=e["last_cols"],
+                          last_eds_bytes=e["last_eds_bytes"], last_seds_bytes=e["last_seds_bytes"])
+        return eds, seds, edges, lambda c0, nc: ctx.msa_copy_columns(c0, nc, n_rows)
+    return MsaSharder(rank, world, dist, slab_fn, lambda m: mini_ctx.msa_transform(m, 0),
+                      lambda m, l: ctx.msa_transform(m, l), device=device)
 
 
 # ======================================================================================================

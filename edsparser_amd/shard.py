@@ -1,13 +1,14 @@
-"""Multi-GPU front end of vcf2eds / eds2leds: one process per GPU under torch.distributed.run, inputs memory-mapped,
-every rank writes its piece of the output files at its global offset (no gather through one rank).
+"""Multi-GPU front end of msa2eds / vcf2eds / eds2leds: one process per GPU under torch.distributed.run, inputs
+memory-mapped, every rank writes its piece of the output files at its global offset (no gather through one rank).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m edsparser_amd.shard \\
-        vcf2eds -i x.vcf -r ref.fa [-o out.eds] [-s out.seds] [-l CONTEXT]
+        msa2eds -i x.msa [-o out.eds] [-s out.seds] [-l CONTEXT]
+    python -m torch.distributed.run ... -m edsparser_amd.shard vcf2eds -i x.vcf -r ref.fa [-o out.eds] [-s out.seds] [-l CONTEXT]
     python -m torch.distributed.run ... -m edsparser_amd.shard eds2leds -i x.eds -l CONTEXT [-s x.seds] [-o out.leds] [--full]
 
-Flags and default file names are the single-GPU CLIs' (reference vcf2eds.cpp:36-43,159-180; eds2leds.cpp:38-46,161-162).
-The partitions are multigpu.VcfSharder (reference-position ranges) and multigpu.MergeSharder (symbol ranges);
-msa2eds over several GPUs is the column-slab stitch that bench.py drives (device-resident slabs).
+Flags and default file names are the single-GPU CLIs' (reference msa2eds.cpp:35-41,139-160; vcf2eds.cpp:36-43,159-180;
+eds2leds.cpp:38-46,161-162).  The partitions are multigpu.MsaSharder (column slabs of every row + the boundary stitch),
+multigpu.VcfSharder (reference-position ranges) and multigpu.MergeSharder (symbol ranges).
 """
 import argparse
 import mmap
@@ -73,6 +74,24 @@ def run_vcf2eds(a, rank, world, dist, vcf_sharder, merge_sharder):
     return eds_path, seds_path, res["stats"]
 
 
+def run_msa2eds(a, rank, world, dist, msa_sharder):
+    if os.path.splitext(a.input)[1] != ".msa":
+        raise SystemExit("Error: Input file must be an MSA file (.msa)")
+    msa = map_file(a.input)
+    stem, d = os.path.splitext(os.path.basename(a.input))[0], os.path.dirname(a.input)
+    if a.context_length > 0:                                   # msa2eds.cpp:139-160
+        suffix = "_l%d" % a.context_length
+        eds_path = a.output or os.path.join(d, stem + suffix + ".leds")
+        seds_path = a.sources or os.path.join(os.path.dirname(eds_path), stem + suffix + ".seds")
+    else:
+        eds_path = a.output or os.path.join(d, stem + ".eds")
+        seds_path = a.sources or os.path.join(os.path.dirname(eds_path), os.path.splitext(os.path.basename(eds_path))[0] + ".seds")
+    res = msa_sharder.run(msa, a.context_length)
+    write_piece(eds_path, res["eds"], res["eds_offset"], res["eds_total"], rank, dist)
+    write_piece(seds_path, res["seds"], res["seds_offset"], res["seds_total"], rank, dist)
+    return eds_path, seds_path, res
+
+
 def run_eds2leds(a, rank, world, dist, merge_sharder):
     if a.context_length <= 0:
         raise SystemExit("Error: context_length must be > 0 for l-EDS transformation")
@@ -92,6 +111,11 @@ def run_eds2leds(a, rank, world, dist, merge_sharder):
 def parse(argv):
     ap = argparse.ArgumentParser(prog="edsparser_amd.shard")
     sub = ap.add_subparsers(dest="tool", required=True)
+    m = sub.add_parser("msa2eds")
+    m.add_argument("-i", "--input", required=True)
+    m.add_argument("-o", "--output", default="")
+    m.add_argument("-s", "--sources", default="")
+    m.add_argument("-l", "--context-length", type=int, default=0)
     v = sub.add_parser("vcf2eds")
     v.add_argument("-i", "--input", required=True)
     v.add_argument("-r", "--reference", required=True)
@@ -126,7 +150,12 @@ def main(argv=None):
     try:
         ctx = Context(local_rank)                              # fails loudly without a gfx950 device
         ms = mg.gpu_merge_sharder(ctx, rank, world, dist)
-        if a.tool == "vcf2eds":
+        if a.tool == "msa2eds":
+            eds_path, seds_path, res = run_msa2eds(a, rank, world, dist, mg.gpu_msa_sharder(ctx, Context(local_rank), rank, world, dist))
+            if rank == 0:
+                print("Transformation complete!\n  Output: \"%s\"\n  Sources: \"%s\"\n  Column slabs: %d%s"
+                      % (eds_path, seds_path, world if res["partitioned"] else 1, "" if res["partitioned"] else " (not partitioned)"))
+        elif a.tool == "vcf2eds":
             eds_path, seds_path, stats = run_vcf2eds(a, rank, world, dist, mg.gpu_vcf_sharder(ctx, rank, world, dist), ms)
             if rank == 0:
                 print("Transformation complete!\n  Output: \"%s\"\n  Sources: \"%s\"\n" % (eds_path, seds_path))

@@ -23,13 +23,26 @@ def _worker(rank, world, port, tool, argv):
         a = shard.parse(argv)
         ms = mg.MergeSharder(rank, world, dist, lambda e, s, l, c, h, t: o.merge_range(e, s, l, c, h, t),
                              lambda e, s, l, c: o.merge(e, s, l, c))
-        if tool == "vcf2eds":
+        if tool == "msa2eds":
+            shard.run_msa2eds(a, rank, world, dist, _oracle_msa_sharder(mg, rank, world, dist))
+        elif tool == "vcf2eds":
             vs = mg.VcfSharder(rank, world, dist, o.vcf_index, o.vcf_sort_order, o.vcf_range)
             shard.run_vcf2eds(a, rank, world, dist, vs, ms)
         else:
             shard.run_eds2leds(a, rank, world, dist, ms)
     finally:
         dist.destroy_process_group()
+
+
+def _oracle_msa_sharder(mg, rank, world, dist):
+    """MsaSharder with the oracle in place of the C ABI: slab text from oracle.msa, edges from the slab's rows."""
+    from test_multigpu_cpu import edges_of, rows_of
+
+    def slab_fn(image, n_rows, ncols):
+        rows = rows_of(image)
+        e, s = o.msa(image, 0)
+        return e, s, edges_of(rows, 0, ncols, e, s), lambda a, n: b"".join(r[a:a + n] for r in rows)
+    return mg.MsaSharder(rank, world, dist, slab_fn, lambda m: o.msa(m, 0), lambda m, l: o.msa(m, l))
 
 
 def _run(tool, argv):
@@ -74,3 +87,39 @@ def test_eds2leds_two_ranks_write_their_pieces(tmp_path, linear):
     assert (tmp_path / "g_l8.leds").read_bytes() == want[0]
     if linear:
         assert (tmp_path / "g_l8.seds").read_bytes() == want[1]
+
+
+@pytest.mark.parametrize("seed,lw,l", [(1, None, 0), (2, 7, 0), (3, 60, 0), (4, None, 0), (5, 13, 0), (6, None, 3)])
+def test_msa2eds_two_ranks_cut_their_column_slabs(tmp_path, seed, lw, l):
+    """File-based msa2eds over two ranks: every rank maps its column slab of every row (wrapped and one-line rows,
+    with and without a trailing newline), stitches, and writes its piece; l > 0 is not partitioned (rank 0 alone)."""
+    from msa_cases import random_msa
+    rng = random.Random(900 + seed)
+    S, L = rng.randint(2, 9), rng.randint(30, 400)
+    msa = random_msa(rng, S=S, L=L, lw=lw or 10 ** 6, trailing_newline=seed % 2 == 1, p_var=rng.choice([0.05, 0.3, 0.7]))
+    (tmp_path / "a.msa").write_bytes(msa)
+    _run("msa2eds", ["msa2eds", "-i", str(tmp_path / "a.msa")] + (["-l", str(l)] if l else []))
+    want = o.msa(msa, l)
+    base = "a_l%d" % l if l else "a"
+    assert (tmp_path / (base + (".leds" if l else ".eds"))).read_bytes() == want[0]
+    assert (tmp_path / (base + ".seds")).read_bytes() == want[1]
+
+
+def test_msa_layout_and_slab_images():
+    """The slab cut addr(s, c) = start[s] + c + c / line_width (msa_transforms.cpp:268-269) against plain row slicing."""
+    from edsparser_amd import multigpu as mg
+    from msa_cases import random_msa
+    from test_multigpu_cpu import rows_of
+    rng = random.Random(77)
+    for it in range(200):
+        S, L = rng.randint(2, 6), rng.randint(2, 90)
+        lw = rng.choice([10 ** 6, 1, 3, 7, 60])
+        msa = random_msa(rng, S=S, L=L, lw=lw, trailing_newline=rng.random() < 0.5)
+        lay = mg.msa_layout(msa)
+        assert lay is not None and len(lay[0]) == S and lay[3] == L, (it, lw)
+        rows = rows_of(msa)
+        c0 = rng.randint(0, L - 1)
+        c1 = rng.randint(c0 + 1, L)
+        assert mg.msa_slab_image(msa, lay, c0, c1) == b"".join(b">r\n" + r[c0:c1] + b"\n" for r in rows), (it, lw, c0, c1)
+    assert mg.msa_layout(b"") is None and mg.msa_layout(b"ACGT\n") is None and mg.msa_layout(b">a\nACGT\n") is None
+    assert mg.msa_layout(b">a\nACGT\n>b\nAC\n") is None            # ragged rows: left to the unpartitioned transform

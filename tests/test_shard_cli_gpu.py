@@ -50,3 +50,17 @@ def test_eds2leds_front_end_and_error_exit(tmp_path):
     (tmp_path / "bad.eds").write_bytes(b"{A,C}{G")
     r = _launch(["eds2leds", "-i", str(tmp_path / "bad.eds"), "-l", "3"])
     assert r.returncode != 0 and "Error: Expected '}'" in r.stderr
+
+
+@pytest.mark.parametrize("lw", [None, 60])
+def test_msa2eds_front_end(tmp_path, lw):
+    """Two ranks, each with its column slab of every row of the file; the stitched pieces equal the oracle's output."""
+    from msa_cases import random_msa
+    rng = random.Random(79)
+    msa = random_msa(rng, S=40, L=30000, lw=lw or 10 ** 6, p_var=0.06)
+    (tmp_path / "a.msa").write_bytes(msa)
+    r = _launch(["msa2eds", "-i", str(tmp_path / "a.msa")])
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = o.msa(msa, 0)
+    assert (tmp_path / "a.eds").read_bytes() == want[0] and (tmp_path / "a.seds").read_bytes() == want[1]
+    assert "Column slabs: 2" in r.stdout
