@@ -26,6 +26,15 @@ class VcfStats(ctypes.Structure):
                  "skipped_unsupported_sv", "variant_groups")]
 
 
+class EdsStatistics(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_uint64) for n in ("n_symbols", "n_chars", "n_strings", "num_degenerate_symbols",
+                                                "total_change_size", "num_common_chars", "num_empty_strings",
+                                                "min_context_length", "max_context_length", "num_context_blocks")] +
+                [("avg_context_length", ctypes.c_double)] +
+                [(n, ctypes.c_uint64) for n in ("has_sources", "num_paths", "max_paths_per_string", "total_paths")] +
+                [("avg_paths_per_string", ctypes.c_double), ("is_leds", ctypes.c_int)])
+
+
 class MsaInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in
                 ("n_rows", "n_cols", "line_width", "n_variant_cols", "n_segments", "msa_bytes",
@@ -68,6 +77,8 @@ def load_library():
                                     ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, P(_Buf), P(_Buf)]
     lib.edsx_vcf_transform.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                        ctypes.c_size_t, ctypes.c_uint32, P(_Buf), P(_Buf), P(VcfStats)]
+    lib.edsx_eds_stats.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                   ctypes.c_uint32, P(EdsStatistics)]
     lib.edsx_leds_tokenised_on_device.argtypes = [ctypes.c_void_p]
     lib.edsx_vcf_tokenised_on_device.argtypes = [ctypes.c_void_p]
     lib.edsx_leds_merge_range.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
@@ -149,6 +160,13 @@ class Context:
         self._check(self._lib.edsx_leds_merge(self._h, eds, len(eds), sb, len(sb) if sb is not None else 0,
                                               context_len, 1 if compact else 0, ctypes.byref(o), ctypes.byref(so)))
         return self._take(o), self._take(so)
+
+    def eds_stats(self, eds, seds=None, context_len=0):
+        """Statistics (EDS::Statistics) and is_leds(context_len) of an .eds (+ .seds) text as a dict."""
+        st = EdsStatistics()
+        self._check(self._lib.edsx_eds_stats(self._h, eds, len(eds), seds, len(seds) if seds is not None else 0,
+                                             context_len, ctypes.byref(st)))
+        return {n: getattr(st, n) for n, _ in EdsStatistics._fields_}
 
     def vcf_transform(self, vcf, fasta, context_len=0):
         e, s, st = _Buf(), _Buf(), VcfStats()

@@ -187,6 +187,28 @@ int edsx_leds_merge(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const ui
     });
 }
 
+int edsx_eds_stats(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const uint8_t* seds, size_t seds_size,
+                   uint32_t context_len, edsx_eds_statistics* out)
+{
+    if (out) std::memset(out, 0, sizeof(*out));
+    return guarded(ctx, [&] {
+        if (!out || (!eds && eds_size)) throw ParamError("null argument");
+        static const uint8_t none = 0;
+        EdsStats s{};
+        ctx->merge.stats(eds ? eds : &none, eds_size, seds, seds_size, context_len, s, nullptr);
+        out->n_symbols = s.n_symbols; out->n_chars = s.n_chars; out->n_strings = s.n_strings;
+        out->num_degenerate_symbols = s.num_degenerate; out->total_change_size = s.total_change_size;
+        out->num_common_chars = s.num_common_chars; out->num_empty_strings = s.num_empty_strings;
+        out->min_context_length = s.min_context; out->max_context_length = s.max_context;
+        out->num_context_blocks = s.num_context_blocks;
+        out->avg_context_length = s.num_context_blocks ? (double)s.num_common_chars / (double)s.num_context_blocks : 0.0;   // eds.cpp:428-432
+        out->has_sources = s.has_sources; out->num_paths = s.num_paths; out->max_paths_per_string = s.max_paths_per_string;
+        out->total_paths = s.total_paths;
+        out->avg_paths_per_string = (s.has_sources && s.n_strings) ? (double)s.total_paths / (double)s.n_strings : 0.0;   // eds.cpp:501-503
+        out->is_leds = (int)s.is_leds;
+    });
+}
+
 int edsx_leds_tokenised_on_device(const edsx_ctx* ctx) { return ctx && ctx->merge.tokenised_on_device() ? 1 : 0; }
 
 int edsx_leds_merge_range(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const uint8_t* seds, size_t seds_size,

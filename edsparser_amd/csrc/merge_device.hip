@@ -627,12 +627,11 @@ bool MergePipeline::tokenize_device(const uint8_t* eds, size_t eds_n, const uint
     return true;
 }
 
-void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l, bool compact,
-                        HostBytes& out, HostBytes& seds_out, hipStream_t st, MergeShard* shard)
+// Tokenise (on the device when the text is plain, else on the host) and leave the round-0 arrays in HBM: per symbol
+// size / first string / single-string length, per string its length (elen_) and, with sources, its path bitset.
+void MergePipeline::prepare(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, bool linear, hipStream_t st,
+                            Loaded& L)
 {
-    if (l == 0) throw ParamError("context_length must be > 0 for l-EDS transformation");   // :322-324
-    const bool linear = seds != nullptr;
-    // EDSX_TRACE=1: wall-clock of the host-visible stages on stderr (every mark follows a stream synchronisation)
     static const bool trace = [] { const char* e = getenv("EDSX_TRACE"); return e && atoi(e); }();
     auto t_last = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
@@ -641,12 +640,12 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
         fprintf(stderr, "[edsx merge] %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-
     // ---- tokenise: on the device when the text is plain (see "device tokenisers"), else on the host
     ctl_.ensure(8 * 16);
-    u64 n0 = 0, m = 0, head_len = 0;
-    u32 W = 1;
-    bool head_single = false, tail_single = false;
+    u64& n0 = L.n0; u64& m = L.m; u64& head_len = L.head_len;
+    u32& W = L.W;
+    bool& head_single = L.head_single; bool& tail_single = L.tail_single;
+    n0 = 0; m = 0; head_len = 0; W = 1; head_single = false; tail_single = false;
     const bool on_device = tokenize_device(eds, eds_n, seds, seds_n, linear, st, n0, m, W, head_single, tail_single, head_len);
     tokenised_on_device_ = on_device;
     mark(on_device ? "upload + device tokenise" : "device tokenise attempt");
@@ -740,12 +739,7 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
             for (int id : sets[sidx]) bits[sidx * W + id / 64] |= 1ull << (id % 64);
     }
 
-    if (n0 == 0) {                                           // empty EDS: save() prints "\n" (quirk 19)
-        out.take(1);
-        out.data[0] = '\n';
-        seds_out.take(0);
-        return;
-    }
+    if (n0 == 0) { L.n0 = 0; L.m = 0; L.W = 1; return; }      // empty EDS
     if (m >= 0xfffffff0ull) throw FormatError("EDS has too many strings for this build");
     head_single = sym_first[1] - sym_first[0] == 1; tail_single = sym_first[n0] - sym_first[n0 - 1] == 1;
     head_len = str_off[1] - str_off[0];
@@ -782,6 +776,130 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     }
     }
     if (!on_device) mark("host tokenise + upload");
+}
+
+// ---- statistics and l-EDS validity as device reductions (eds.cpp:361-505, eds_transforms.cpp:439-468) -------------
+// acc: [0] degenerate symbols [1] sum(size - 1) over them [2] characters of the non-degenerate symbols [3] their number
+//      [4] min / [5] max of their lengths [6] "not an l-EDS" [7] empty strings [8] all characters [9] sum of the set
+//      sizes [10] largest set; orbits[W]: OR of all path sets
+__device__ __forceinline__ u64 wave_sum64(u64 v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ void __launch_bounds__(256) k_eds_stats(SymArrays s, u64 n, const u32* __restrict__ elen, u64 m, const u64* __restrict__ bits,
+                                                   u32 W, u64 l, u64* __restrict__ acc, u64* __restrict__ orbits)
+{
+    const u64 t0 = blockIdx.x * (u64)blockDim.x + threadIdx.x, step = (u64)gridDim.x * blockDim.x;
+    u64 ndeg = 0, change = 0, common = 0, nctx = 0, mn = ~0ull, mx = 0, bad = 0;
+    for (u64 i = t0; i < n; i += step) {
+        const u64 sz = s.size[i];
+        if (sz > 1) {
+            ndeg++; change += sz - 1;
+            if (i + 1 < n && s.size[i + 1] > 1) bad = 1;        // adjacent degenerate symbols (:462-464)
+        } else {
+            const u64 len = s.len1[i];
+            common += len; nctx++;
+            mn = len < mn ? len : mn; mx = len > mx ? len : mx;
+            if (l && i > 0 && i + 1 < n && len < l) bad = 1;     // a short internal common block (:455-457)
+        }
+    }
+    u64 empty = 0, chars = 0, tot = 0, big = 0;
+    for (u64 k = t0; k < m; k += step) {
+        const u64 e = elen[k];
+        empty += e == 0; chars += e;
+        if (bits) {
+            u64 c = 0;
+            for (u32 w = 0; w < W; w++) c += (u64)__builtin_popcountll(bits[k * W + w]);
+            tot += c; big = c > big ? c : big;
+        }
+    }
+    if (bits) {                                                   // OR of all sets, word by word
+        for (u32 w = 0; w < W; w++) {
+            u64 o = 0;
+            for (u64 k = t0; k < m; k += step) o |= bits[k * W + w];
+            for (int sh = 32; sh > 0; sh >>= 1) o |= __shfl_xor(o, sh, 64);
+            if ((threadIdx.x & 63) == 0 && o) atomicOr(&orbits[w], o);
+        }
+    }
+    ndeg = wave_sum64(ndeg); change = wave_sum64(change); common = wave_sum64(common); nctx = wave_sum64(nctx);
+    empty = wave_sum64(empty); chars = wave_sum64(chars); tot = wave_sum64(tot);
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        const u64 a = __shfl_xor(mn, sh, 64), b = __shfl_xor(mx, sh, 64), c = __shfl_xor(big, sh, 64), d = __shfl_xor(bad, sh, 64);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx; big = c > big ? c : big; bad |= d;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (ndeg) atomicAdd(&acc[0], ndeg);
+        if (change) atomicAdd(&acc[1], change);
+        if (common) atomicAdd(&acc[2], common);
+        if (nctx) atomicAdd(&acc[3], nctx);
+        atomicMin(&acc[4], mn); atomicMax(&acc[5], mx);
+        if (bad) atomicOr(&acc[6], 1ull);
+        if (empty) atomicAdd(&acc[7], empty);
+        if (chars) atomicAdd(&acc[8], chars);
+        if (tot) atomicAdd(&acc[9], tot);
+        atomicMax(&acc[10], big);
+    }
+}
+
+void MergePipeline::stats(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l, EdsStats& out,
+                          hipStream_t st)
+{
+    const bool linear = seds != nullptr;
+    Loaded L;
+    prepare(eds, eds_n, seds, seds_n, linear, st, L);
+    out = EdsStats{};
+    out.has_sources = linear ? 1 : 0;
+    out.is_leds = 1;
+    if (L.n0 == 0) return;                                      // empty EDS: all zero (eds.cpp:362-376), trivially an l-EDS
+    const u32 W = linear ? L.W : 0;
+    a_.ensure(8 * (16 + (size_t)W + 1));
+    u64* acc = a_.as<u64>();
+    std::vector<u64> h(16 + W, 0);
+    h[4] = ~0ull;
+    EDSX_HIP(hipMemcpyAsync(acc, h.data(), 8 * h.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_eds_stats, dim3(1024), dim3(256), 0, st, SymArrays{size_[0].as<u64>(), ent_off_[0].as<u64>(), len1_[0].as<u64>()},
+                       L.n0, elen_.as<u32>(), L.m, linear ? bits_.as<u64>() : nullptr, W, (u64)l, acc, acc + 16);
+    EDSX_HIP(hipMemcpyAsync(h.data(), acc, 8 * h.size(), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    EDSX_HIP(hipGetLastError());
+    out.n_symbols = L.n0; out.n_strings = L.m; out.n_chars = h[8];
+    out.num_degenerate = h[0]; out.total_change_size = h[1]; out.num_common_chars = h[2]; out.num_context_blocks = h[3];
+    out.min_context = h[3] ? h[4] : 0; out.max_context = h[5]; out.num_empty_strings = h[7];
+    out.is_leds = (l == 0 || !h[6]) ? 1 : 0;
+    if (linear) {
+        out.total_paths = h[9]; out.max_paths_per_string = h[10];
+        for (u32 w = 0; w < W; w++) out.num_paths += (u64)__builtin_popcountll(h[16 + w]);
+    }
+}
+
+void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l, bool compact,
+                        HostBytes& out, HostBytes& seds_out, hipStream_t st, MergeShard* shard)
+{
+    if (l == 0) throw ParamError("context_length must be > 0 for l-EDS transformation");   // :322-324
+    const bool linear = seds != nullptr;
+    // EDSX_TRACE=1: wall-clock of the host-visible stages on stderr (every mark follows a stream synchronisation)
+    static const bool trace = [] { const char* e = getenv("EDSX_TRACE"); return e && atoi(e); }();
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[edsx merge] %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+
+    Loaded L;
+    prepare(eds, eds_n, seds, seds_n, linear, st, L);
+    t_last = std::chrono::steady_clock::now();
+    const u64 n0 = L.n0, m = L.m, head_len = L.head_len;
+    const u32 W = L.W;
+    const bool head_single = L.head_single, tail_single = L.tail_single;
+    if (n0 == 0) {                                           // empty EDS: save() prints "\n" (quirk 19)
+        out.take(1);
+        out.data[0] = '\n';
+        seds_out.take(0);
+        return;
+    }
     if (shard) {
         shard->head_intact = shard->tail_intact = true;
         if ((shard->head_sentinel && !head_single) || (shard->tail_sentinel && !tail_single) ||

@@ -123,6 +123,23 @@ int edsx_leds_merge_range(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, co
                           uint32_t context_len, int compact, int head_sentinel, int tail_sentinel,
                           edsx_buf* leds, edsx_buf* seds_out, int* head_intact, int* tail_intact);
 
+/* ---- statistics and validation of an EDS / l-EDS (what edsparser-stats prints) ----
+ * Replaces EDS::calculate_statistics / calculate_source_statistics (src/cpp/lib/formats/eds.cpp:361-470, :472-505,
+ * struct EDS::Statistics eds.hpp:107-120) and is_leds (src/cpp/lib/transforms/eds_transforms.cpp:439-468): the text is
+ * tokenised as for edsx_leds_merge and the numbers are device reductions over the per-symbol / per-string arrays.
+ * seds == NULL: no sources (the three path fields stay 0).  Parse errors: as edsx_leds_merge. */
+typedef struct {
+    uint64_t n_symbols, n_chars, n_strings;            /* EDS::length(), size(), cardinality() */
+    uint64_t num_degenerate_symbols, total_change_size, num_common_chars, num_empty_strings;
+    uint64_t min_context_length, max_context_length, num_context_blocks;
+    double   avg_context_length;                       /* num_common_chars / num_context_blocks (0 when there are none) */
+    uint64_t has_sources, num_paths, max_paths_per_string, total_paths;
+    double   avg_paths_per_string;                     /* total_paths / n_strings */
+    int      is_leds;                                  /* is_leds(eds, context_len) */
+} edsx_eds_statistics;
+int edsx_eds_stats(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const uint8_t* seds, size_t seds_size,
+                   uint32_t context_len, edsx_eds_statistics* out);
+
 /* ---- device-resident MSA path (inputs/outputs stay in HBM) ---- */
 
 /* Phase 1: index rows, scan columns, build the segment table and size the outputs.

@@ -330,3 +330,47 @@ extern "C" int oracle_merge_range(const uint8_t* eds, size_t eds_n, const uint8_
         return dynamic_cast<const std::invalid_argument*>(&ex) ? 3 : 2;
     }
 }
+
+// EDS::calculate_statistics eds.cpp:361-470, calculate_source_statistics :472-505, is_leds eds_transforms.cpp:439-468
+extern "C" int oracle_eds_stats(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l,
+                                oracle_eds_statistics* out, char* err, size_t errcap)
+{
+    try {
+        memset(out, 0, sizeof(*out));
+        Eds e;
+        parse_eds(eds, eds_n, e);
+        if (seds) parse_sources(seds, seds_n, e);
+        out->has_sources = seds ? 1 : 0;
+        out->is_leds = is_leds(e, l) ? 1 : 0;
+        if (e.sets.empty()) return 0;                        // :362-376: everything 0
+        uint64_t mn = UINT32_MAX, total_ctx = 0;
+        out->n_symbols = e.sets.size();
+        for (const auto& st : e.sets) {
+            out->n_strings += st.size();
+            if (st.size() > 1) { out->num_degenerate_symbols++; out->total_change_size += st.size() - 1; }   // :398-401
+            else {                                           // :402-417: a context block
+                const uint64_t len = st[0].size();
+                if (len < mn) mn = len;
+                if (len > out->max_context_length) out->max_context_length = len;
+                total_ctx += len; out->num_context_blocks++; out->num_common_chars += len;
+            }
+            for (const auto& str : st) { out->n_chars += str.size(); if (str.empty()) out->num_empty_strings++; }   // :420-426
+        }
+        out->avg_context_length = out->num_context_blocks ? (double)total_ctx / (double)out->num_context_blocks : 0.0;   // :429-433
+        out->min_context_length = mn == UINT32_MAX ? 0 : mn;                                                              // :436-438
+        if (e.has_sources && !e.sources.empty()) {            // :478-503
+            std::set<int> all;
+            for (const auto& ss : e.sources) {
+                if (ss.size() > out->max_paths_per_string) out->max_paths_per_string = ss.size();
+                all.insert(ss.begin(), ss.end());
+                out->total_paths += ss.size();
+            }
+            out->num_paths = all.size();
+            out->avg_paths_per_string = (double)out->total_paths / (double)e.sources.size();
+        }
+        return 0;
+    } catch (const std::exception& ex) {
+        if (err && errcap) { strncpy(err, ex.what(), errcap - 1); err[errcap - 1] = 0; }
+        return dynamic_cast<const std::invalid_argument*>(&ex) ? 3 : 2;
+    }
+}

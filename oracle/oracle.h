@@ -71,6 +71,19 @@ int oracle_merge_range(const uint8_t* eds, size_t eds_n, const uint8_t* seds, si
                        char** out, size_t* out_n, char** seds_out, size_t* seds_out_n,
                        int* head_intact, int* tail_intact, char* err, size_t errcap);
 
+/* EDS::calculate_statistics / calculate_source_statistics (eds.cpp:361-470, :472-505) and is_leds
+ * (eds_transforms.cpp:439-468).  seds == NULL: no sources. */
+typedef struct {
+    uint64_t n_symbols, n_chars, n_strings, num_degenerate_symbols, total_change_size, num_common_chars,
+             num_empty_strings, min_context_length, max_context_length, num_context_blocks;
+    double avg_context_length;
+    uint64_t has_sources, num_paths, max_paths_per_string, total_paths;
+    double avg_paths_per_string;
+    int is_leds;
+} oracle_eds_statistics;
+int oracle_eds_stats(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l,
+                     oracle_eds_statistics* out, char* err, size_t errcap);
+
 void oracle_free(void* p);
 
 #ifdef __cplusplus

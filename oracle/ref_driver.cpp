@@ -75,4 +75,41 @@ extern "C" int ref_vcf(const uint8_t* vcf, size_t vcf_n, const uint8_t* fasta, s
     } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return 2; }
 }
 
+struct ref_eds_statistics {
+    uint64_t n_symbols, n_chars, n_strings, num_degenerate_symbols, total_change_size, num_common_chars,
+             num_empty_strings, min_context_length, max_context_length, num_context_blocks;
+    double avg_context_length;
+    uint64_t has_sources, num_paths, max_paths_per_string, total_paths;
+    double avg_paths_per_string;
+    int is_leds;
+};
+
+// EDS(eds[, seds]) -> get_statistics() + is_leds(l) of the real reference.  num_context_blocks and total_paths are not
+// fields of EDS::Statistics: they are reported as 0 and the tests compare the averages instead.
+extern "C" int ref_eds_stats(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, uint32_t l,
+                             ref_eds_statistics* out, char* err, size_t errcap)
+{
+    try {
+        memset(out, 0, sizeof(*out));
+        const std::string es(reinterpret_cast<const char*>(eds), eds_n);
+        edsparser::EDS e = seds ? edsparser::EDS(es, std::string(reinterpret_cast<const char*>(seds), seds_n)) : edsparser::EDS(es);
+        out->is_leds = edsparser::is_leds(e, l) ? 1 : 0;
+        if (e.empty()) return 0;   // an empty EDS never reaches calculate_statistics in the string constructors: its Statistics are uninitialised
+        const auto st = e.get_statistics();
+        out->n_symbols = e.length(); out->n_chars = e.size(); out->n_strings = e.cardinality();
+        out->num_degenerate_symbols = st.num_degenerate_symbols; out->total_change_size = st.total_change_size;
+        out->num_common_chars = st.num_common_chars; out->num_empty_strings = st.num_empty_strings;
+        out->min_context_length = st.min_context_length; out->max_context_length = st.max_context_length;
+        out->avg_context_length = st.avg_context_length;
+        out->has_sources = e.has_sources() ? 1 : 0;
+        if (e.has_sources()) {   // without sources the reference leaves these three fields uninitialised (eds.cpp:116 never runs :472)
+            out->num_paths = st.num_paths;
+            out->max_paths_per_string = st.max_paths_per_string; out->avg_paths_per_string = st.avg_paths_per_string;
+        }
+        out->is_leds = edsparser::is_leds(e, l) ? 1 : 0;
+        return 0;
+    } catch (const std::invalid_argument& ex) { set_err(err, errcap, ex.what()); return 3;
+    } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return 2; }
+}
+
 extern "C" void ref_free(void* p) { free(p); }

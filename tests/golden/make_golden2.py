@@ -7,6 +7,9 @@ oracle/Makefile) in the build container only; the outputs are committed as data:
                    record order, vcf_transforms.cpp:715-718 / SURVEY quirk 29), and the SURVEY quirk 22-27 shapes
                    (unsorted + overlap + multi-allelic <DEL>, no samples + <INV> + bad line, hom-ALT / missing /
                    haploid GT, l > 0, POS beyond the reference, REF straddling the end).
+  gen2_stats.json  EDS::Statistics + is_leds(l) (eds.cpp:361-505, eds_transforms.cpp:439-468) of the inputs AND of the
+                   reference's outputs of every case in gen_merge.json and of the chain cases below (cases refer to
+                   their texts by index, the numbers are the reference's).
   gen2_merge.json  merges of 500..2000 symbols that take 6 and more rounds (LINEAR with 1 and 3 threads, and
                    CARTESIAN), plus BASELINE configs[0]'s shape (genrandomeds @5 %, eds2leds -l 10, CARTESIAN) at
                    0.2 MB.  Expected outputs above 64 KB are stored as length + SHA-256 of the reference's bytes.
@@ -156,6 +159,29 @@ def rounds_of(eds, l):
     return r
 
 
+def stats_texts(sc, gen_merge_cases, gen2_merge_cases):
+    """(eds, seds) bytes a statistics case refers to."""
+    c = (gen_merge_cases if sc["src"] == "gen_merge" else gen2_merge_cases)[sc["index"]]
+    has_src = c["seds"] is not None
+    if sc["what"] == "input":
+        return c["eds"].encode(), c["seds"].encode() if has_src else None
+    ex = c["expect"]
+    out = ex["out"]["text"] if isinstance(ex["out"], dict) else ex["out"]
+    so = ex["seds_out"]["text"] if isinstance(ex["seds_out"], dict) else ex["seds_out"]
+    return out.encode(), so.encode() if has_src else None
+
+
+def stats_case_run(fn, sc, gen_merge_cases, gen2_merge_cases):
+    eds, seds = stats_texts(sc, gen_merge_cases, gen2_merge_cases)
+    try:
+        d = fn(eds, seds, sc["l"])
+        d = dict(d)
+        d.pop("num_context_blocks", None); d.pop("total_paths", None)
+        return d
+    except Exception as ex:  # noqa: BLE001 — OracleError / EdsxError
+        return {"error": getattr(ex, "message", None) or str(ex)}
+
+
 def main():
     check = "--check" in sys.argv
     if not o.have_ref():
@@ -200,10 +226,33 @@ def main():
     c0["expect"] = {"out": pack(out), "seds_out": pack(so)}
     print("  merge %s: %d bytes in, %d out, %.1f s" % (c0["name"], len(eds), len(out), time.time() - t1), flush=True)
 
+    # ---- statistics / is_leds of inputs and outputs, by the reference's EDS class
+    def ref_stats(eds, seds, l):
+        try:
+            d = o.ref_eds_stats(eds, seds, l)
+            d.pop("num_context_blocks"); d.pop("total_paths")      # not part of EDS::Statistics
+            return d
+        except o.OracleError as ex:
+            return {"error": str(ex)}
+    stats_cases = []
+    gm = json.load(open(os.path.join(HERE, "gen_merge.json")))["cases"]
+    for src, cases in (("gen_merge", gm), ("gen2_merge", merge_cases)):
+        for i, c in enumerate(cases):
+            seds = c["seds"].encode() if c["seds"] is not None else None
+            stats_cases.append({"src": src, "index": i, "what": "input", "l": c["l"], "stats": ref_stats(c["eds"].encode(), seds, c["l"])})
+            ex = c["expect"]
+            if "error" not in ex and "text" in ex.get("out", {"text": ex.get("out")}) if isinstance(ex.get("out"), dict) else "error" not in ex:
+                out = ex["out"]["text"] if isinstance(ex["out"], dict) else ex["out"]
+                so = ex["seds_out"]["text"] if isinstance(ex["seds_out"], dict) else ex["seds_out"]
+                stats_cases.append({"src": src, "index": i, "what": "output", "l": c["l"],
+                                    "stats": ref_stats(out.encode(), so.encode() if seds is not None else None, c["l"])})
+    print("stats: %d cases" % len(stats_cases))
+
     prov = ("Generated by tests/golden/make_golden2.py from the reference library compiled in the build container "
             "(oracle/_ref); 'expect' is the reference's output (bytes above 64 KB as length + sha256).")
     docs = {"gen2_vcf.json": {"_provenance": prov, "cases": vcf_cases},
-            "gen2_merge.json": {"_provenance": prov, "cases": merge_cases, "configs0": c0}}
+            "gen2_merge.json": {"_provenance": prov, "cases": merge_cases, "configs0": c0},
+            "gen2_stats.json": {"_provenance": prov, "cases": stats_cases}}
     for name, doc in docs.items():
         path = os.path.join(HERE, name)
         if check:
@@ -223,6 +272,10 @@ def main():
             bad += 1; print("MERGE MISMATCH", c["name"])
         if "expect_threads3" in c and c["expect_threads3"] != c["expect"]:
             bad += 1; print("REFERENCE threads 1 vs 3 differ", c["name"])
+    for sc in stats_cases:
+        got = stats_case_run(o.eds_stats, sc, gm, merge_cases)
+        if got != sc["stats"]:
+            bad += 1; print("STATS MISMATCH", sc["src"], sc["index"], sc["what"], got, sc["stats"])
     out, so = o.merge(eds, None, 10, True)
     if not (matches(c0["expect"]["out"], out) and matches(c0["expect"]["seds_out"], so)):
         bad += 1; print("MERGE MISMATCH configs0")

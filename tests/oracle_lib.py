@@ -24,6 +24,39 @@ class VcfStats(ctypes.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class EdsStatistics(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_uint64) for n in ("n_symbols", "n_chars", "n_strings", "num_degenerate_symbols",
+                                                "total_change_size", "num_common_chars", "num_empty_strings",
+                                                "min_context_length", "max_context_length", "num_context_blocks")] +
+                [("avg_context_length", ctypes.c_double)] +
+                [(n, ctypes.c_uint64) for n in ("has_sources", "num_paths", "max_paths_per_string", "total_paths")] +
+                [("avg_paths_per_string", ctypes.c_double), ("is_leds", ctypes.c_int)])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def _stats_call(fn, eds, seds, l):
+    e, en = _buf(eds)
+    s, sn = _buf(seds)
+    st = EdsStatistics()
+    err = ctypes.create_string_buffer(512)
+    rc = fn(e, ctypes.c_size_t(en), s, ctypes.c_size_t(sn), ctypes.c_uint32(l), ctypes.byref(st), err, ctypes.c_size_t(512))
+    if rc != 0:
+        raise OracleError(rc, err.value.decode(errors="replace"))
+    return st.as_dict()
+
+
+def eds_stats(eds, seds=None, l=0):
+    """EDS::Statistics + is_leds(l) by the oracle restatement."""
+    return _stats_call(_load().oracle_eds_stats, eds, seds, l)
+
+
+def ref_eds_stats(eds, seds=None, l=0):
+    """... by the real reference (build container only); num_context_blocks / total_paths are not reported (0)."""
+    return _stats_call(_load_ref().ref_eds_stats, eds, seds, l)
+
+
 def build_oracle():
     """Compile oracle/ (and oracle/_ref when /root/reference is present)."""
     subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)

@@ -88,3 +88,44 @@ def test_vcf2eds_and_eds2leds_cli_gpu(tmp_path):
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "test_iterative_l4.leds").read_bytes() == open(os.path.join(g, "eds/test_iterative_l4.eds"), "rb").read()
     assert "Output mode: compact" in r.stdout and "Threads: 1 (sequential)" in r.stdout
+
+
+@pytest.mark.gpu
+def test_edsparser_stats_cli_gpu(tmp_path):
+    """edsparser-stats: the numbers of the text and JSON reports against the oracle's EDS::Statistics restatement
+    (itself pinned by the reference's numbers in tests/golden/gen2_stats.json)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as o
+    _build_host()
+    eds = b"{ACGTAC}{A,ACA,}{CGTTTTT}{,T}{GG}{C,G}{TTTTTTTTTT}"
+    seds = b"{0}{1,3}{2}{4}{0}{1,2}{3,4}{0}{1,2,3}{4}{0}"
+    (tmp_path / "x.eds").write_bytes(eds)
+    (tmp_path / "x.seds").write_bytes(seds)
+    exe = os.path.join(BUILD, "edsparser-stats")
+    want = o.eds_stats(eds, seds, 0)
+    r = subprocess.run([exe, "-i", str(tmp_path / "x.eds"), "-s", str(tmp_path / "x.seds"), "--json"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout)
+    assert j["structure"] == {"n_symbols": want["n_symbols"], "N_characters": want["n_chars"], "m_strings": want["n_strings"],
+                              "degenerate_symbols": want["num_degenerate_symbols"],
+                              "regular_symbols": want["n_symbols"] - want["num_degenerate_symbols"]}
+    assert j["context_lengths"]["min"] == want["min_context_length"] and j["context_lengths"]["max"] == want["max_context_length"]
+    assert abs(j["context_lengths"]["avg"] - want["avg_context_length"]) < 0.006
+    assert j["variations"] == {"total_change_size": want["total_change_size"], "common_characters": want["num_common_chars"],
+                               "empty_strings": want["num_empty_strings"]}
+    assert j["sources"]["loaded"] is True and j["sources"]["num_paths"] == want["num_paths"]
+    assert j["sources"]["max_paths_per_string"] == want["max_paths_per_string"]
+    assert j["recommendations"]["needs_transformation"] is True and j["file"]["storage_mode"] == "METADATA_ONLY"
+    r = subprocess.run([exe, "-i", str(tmp_path / "x.eds"), "--full", "--verbose"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Storage Mode: FULL (all data in RAM)" in r.stdout and "Detailed Metrics:" in r.stdout
+    assert "  Number of symbols (n):        %12d" % want["n_symbols"] in r.stdout
+    assert "  Minimum:                      %12d" % want["min_context_length"] in r.stdout
+    assert "Sources (pangenome paths):" not in r.stdout and "[Performance] Runtime:" in r.stderr
+    r = subprocess.run([exe, "-i", str(tmp_path / "missing.eds")], capture_output=True, text=True)
+    assert r.returncode == 1 and "not found" in r.stderr
+    (tmp_path / "bad.eds").write_bytes(b"{A,C}{G")
+    r = subprocess.run([exe, "-i", str(tmp_path / "bad.eds")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Error: Expected '}'" in r.stderr

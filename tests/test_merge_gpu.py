@@ -84,6 +84,33 @@ def test_baseline_config0_shape(ctx):
     assert _matches(c0["expect"]["out"], out) and _matches(c0["expect"]["seds_out"], so)
 
 
+def test_eds_statistics_and_is_leds(ctx):
+    """edsx_eds_stats (device reductions) against the reference's EDS::Statistics / is_leds numbers for ~800 texts
+    (inputs and outputs of the merge fixtures), error texts included."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden2 import stats_case_run
+    gm = json.load(open(os.path.join(GOLDEN, "gen_merge.json")))["cases"]
+    g2 = json.load(open(os.path.join(GOLDEN, "gen2_merge.json")))["cases"]
+    for sc in json.load(open(os.path.join(GOLDEN, "gen2_stats.json")))["cases"]:
+        assert stats_case_run(ctx.eds_stats, sc, gm, g2) == sc["stats"], sc
+
+
+def test_merge_outputs_validate_as_leds(ctx):
+    """Self-check: what edsx_leds_merge writes is an l-EDS by the device validator, for random larger inputs."""
+    rng = random.Random(99)
+    for _ in range(40):
+        linear = rng.random() < 0.6
+        eds, seds = _random_eds(rng, rng.randint(2, 400), 6, linear)
+        l = rng.choice([1, 2, 4, 8, 16])
+        got = _run(ctx, eds, seds, l, False)          # FULL brackets: COMPACT text drops an empty single-string symbol
+        if "error" in got:
+            continue
+        st = ctx.eds_stats(got["out"].encode(), got["seds_out"].encode() if linear else None, l)
+        assert st["is_leds"] == 1, (eds, l)
+        assert st == o.eds_stats(got["out"].encode(), got["seds_out"].encode() if linear else None, l)
+
+
 def test_l0_is_invalid_argument(ctx):
     got = _run(ctx, b"{A}", None, 0)
     assert got["code"] == 3

@@ -3,6 +3,7 @@ hot path (tests/cpp/test_msa.cpp strings, data/ goldens), the SURVEY KATs and th
 generated from the real reference library (tests/golden/make_golden.py)."""
 import json
 import os
+import sys
 
 import pytest
 
@@ -156,6 +157,17 @@ def test_merge_baseline_config0_shape():
     assert len(eds) == c0["eds_len"] and hashlib.sha256(eds).hexdigest() == c0["eds_sha256"]
     out, so = o.merge(eds, None, c0["l"], c0["compact"])
     assert _matches(c0["expect"]["out"], out) and _matches(c0["expect"]["seds_out"], so)
+
+
+def test_eds_statistics_and_is_leds_generated_goldens():
+    """EDS::Statistics + is_leds of ~800 inputs / outputs: the oracle restatement against the reference's numbers."""
+    sys.path.insert(0, GOLDEN)
+    from make_golden2 import stats_case_run
+    gm, g2 = _load("gen_merge.json")["cases"], _load("gen2_merge.json")["cases"]
+    cases = _load("gen2_stats.json")["cases"]
+    assert len(cases) >= 700 and any(c["stats"].get("is_leds") == 0 for c in cases)
+    for sc in cases:
+        assert stats_case_run(o.eds_stats, sc, gm, g2) == sc["stats"], sc
 
 
 @pytest.mark.skipif(not o.have_ref(), reason="oracle/_ref not built (reference absent on this box)")
