@@ -68,7 +68,16 @@ def cpu_baseline(ctx, torch, rows, sample_mb, vfrac, seed, l):
     t0 = time.perf_counter()
     e, s = oracle_lib.msa(host, l)
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port", "cpu_model": model,
+            "host_cores": os.cpu_count(),
             "sample": "%d rows x %d columns (%.0f MB in, %.1f s), same generator and site fraction"
                       % (rows, cols, n / 1e6, dt)}
 

@@ -36,6 +36,7 @@ template <class F> int guarded(edsx_ctx* ctx, F&& f)
         return EDSX_OK;
     } catch (const FormatError& ex) { ctx->err = ex.what(); return EDSX_ERR_INVALID_FORMAT;
     } catch (const ParamError& ex) { ctx->err = ex.what(); return EDSX_ERR_INVALID_PARAMETER;
+    } catch (const LimitError& ex) { ctx->err = ex.what(); return EDSX_ERR_BUILD_FAILED;
     } catch (const DeviceError& ex) { ctx->err = ex.what(); return EDSX_ERR_BUILD_FAILED;
     } catch (const std::bad_alloc&) { ctx->err = "out of host memory"; return EDSX_ERR_BUILD_FAILED;
     } catch (const std::exception& ex) { ctx->err = ex.what(); return EDSX_ERR_UNKNOWN; }

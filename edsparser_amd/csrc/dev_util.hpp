@@ -39,9 +39,18 @@ public:
             EDSX_HIP(hipStreamSynchronize(st));
             return;
         }
-        static std::mutex mu;
-        std::lock_guard<std::mutex> lock(mu);                  // one set of staging buffers per process
-        static Stage sg;
+        // one set of staging buffers and events per device (events belong to the device that is current when they
+        // are created; contexts on different GPUs of one process download side by side)
+        int dev = 0;
+        EDSX_HIP(hipGetDevice(&dev));
+        static Stage stages[MAX_DEVICES];
+        if (dev < 0 || dev >= MAX_DEVICES) {
+            EDSX_HIP(hipMemcpyAsync(dst, dev_src, n, hipMemcpyDeviceToHost, st));
+            EDSX_HIP(hipStreamSynchronize(st));
+            return;
+        }
+        Stage& sg = stages[dev];
+        std::lock_guard<std::mutex> lock(sg.mu);
         sg.ensure();
         uint8_t* out = static_cast<uint8_t*>(dst);
         const uint8_t* src = static_cast<const uint8_t*>(dev_src);
@@ -71,7 +80,9 @@ public:
 private:
     static constexpr size_t MIN_BYTES = (size_t)16 << 20, CHUNK = (size_t)32 << 20;
     static constexpr unsigned THREADS = 8;
+    static constexpr int MAX_DEVICES = 16;
     struct Stage {
+        std::mutex mu;
         uint8_t* pin[2] = {nullptr, nullptr};
         hipEvent_t ev[2];
         bool ready = false;

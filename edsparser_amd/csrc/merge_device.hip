@@ -209,6 +209,10 @@ __global__ void k_fin_write(FinParams p, u64 nstr)
             if (wr) *o = first ? '{' : ',';
             o += wr ? 1 : 0;
         }
+        // Depth of an entry's merge tree <= number of rounds its symbol took part in.  Every round merges at least half
+        // of each run of mergeable pairs (greedy non-overlapping pairs, eds_transforms.cpp:63-66), so a symbol built from
+        // 2^32 leaves - more than the pool can hold - is at most ~33 levels deep plus the rounds in which a product
+        // collapsed and reopened a run; 96 is far beyond what fits in the 32-bit entry pool.  An overflow still raises.
         u32 stack[96];
         int sp = 0;
         stack[sp++] = p.fin_ent[t];

@@ -2726,8 +2726,9 @@ void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t s
                                                  rows_.as<u64>(), (u64)ROW_CAP));
     EDSX_HIP(hipMemcpyAsync(&h_, dh, sizeof(MsaHdr), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
+    if (h_.status & ST_TOO_MANY_ROWS) throw LimitError(status_message(ST_TOO_MANY_ROWS));
     if (h_.status) throw FormatError(status_message(h_.status));
-    if (h_.S > MAX_ROWS) throw FormatError(status_message(ST_TOO_MANY_ROWS));
+    if (h_.S > MAX_ROWS) throw LimitError(status_message(ST_TOO_MANY_ROWS));
     {   // padding for the column scan's 16-row loads (at most 256 threads x 16 rows past the last one)
         const u64 padded = std::min<u64>(ROW_CAP, (h_.S + 15) / 16 * 16 + 4096);
         hipLaunchKernelGGL(k_pad_rows, dim3(4), dim3(256), 0, st, rows_.as<u64>(), h_.S, padded);
@@ -2809,14 +2810,14 @@ void MsaPipeline::plan_body(hipStream_t st)
     const u64 ntiles = (Draw + W - 1) / W;
     const size_t colbuf_bytes = cfg == 0 ? 96 * 1024 : 64 * 1024;
     if (ntiles > 0x7fffffffull) throw FormatError("MSA too large for one launch");
-    if (colbuf_bytes < (size_t)S * 8) throw FormatError(status_message(ST_TOO_MANY_ROWS));
+    if (colbuf_bytes < (size_t)S * 8) throw LimitError(status_message(ST_TOO_MANY_ROWS));
 
     K1Params kp;
     kp.file = d_msa; kp.row_start = rows_.as<u64>(); kp.hdr = dh;
     kp.Vraw = vraw_.as<u64>(); kp.word_slot = wslot_.as<u64>(); kp.vc = vc_.as<uint8_t>();
     kp.vc_cap_cols = vc_cap_cols_; kp.Draw = Draw; kp.lw = lw; kp.S = (u32)S; kp.Spad = Spad;
     kp.cpr_log2 = cpr_log2; kp.cap_cols = (u32)(colbuf_bytes / Spad); kp.ntiles = ntiles;
-    if (kp.cap_cols == 0) throw FormatError(status_message(ST_TOO_MANY_ROWS));
+    if (kp.cap_cols == 0) throw LimitError(status_message(ST_TOO_MANY_ROWS));
     const bool lane_rows = hold && RPT == 16;             // thread rows = 16 consecutive rows = 16 consecutive vc bytes
     // fused grouping: context length 0 (segments = runs), one-line rows (raw position = column), wave-per-segment code
     static int fuse_env = -1;

@@ -15,6 +15,9 @@ namespace edsx {
 
 struct FormatError : std::runtime_error { using std::runtime_error::runtime_error; };   // EDSX_ERR_INVALID_FORMAT
 struct ParamError : std::runtime_error { using std::runtime_error::runtime_error; };    // EDSX_ERR_INVALID_PARAMETER
+// a well-formed input beyond a limit of this build (more than MsaPipeline::MAX_ROWS sequences): EDSX_ERR_BUILD_FAILED,
+// not a format error - the reference has no such limit
+struct LimitError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 // grow-only device allocation
 struct DevBuf {

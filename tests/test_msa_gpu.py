@@ -62,6 +62,19 @@ def test_format_errors(ctx):
         assert ei.value.code == 2, bad
 
 
+def test_row_limit_is_a_build_limit_not_a_format_error(ctx):
+    """More than 8192 sequences: a limit of this build (LDS budget of the grouping kernels), reported as
+    EDSX_ERR_BUILD_FAILED (4) with its own text; 8192 rows still transform and equal the oracle."""
+    import edsparser_amd
+    rows = [b"ACGTACGTAC" if i % 3 else b"ACGTTCGTAC" for i in range(8193)]
+    big = b"".join(b">s%d\n" % i + r + b"\n" for i, r in enumerate(rows))
+    with pytest.raises(edsparser_amd.EdsxError) as ei:
+        ctx.msa_transform(big, 0)
+    assert ei.value.code == 4 and "more sequences than this build supports" in ei.value.message
+    ok = b"".join(b">s%d\n" % i + r + b"\n" for i, r in enumerate(rows[:8192]))
+    assert ctx.msa_transform(ok, 0) == o.msa(ok, 0)
+
+
 def test_trailing_blank_lines_tolerated(ctx):
     msa = b">a\nACGT\n>b\nACGA\n\n\n"
     assert ctx.msa_transform(msa, 0) == o.msa(msa, 0)
@@ -252,6 +265,38 @@ def test_host_buffer_path_large_outputs_equal_device_path(ctx, L):
     assert (len(eds), len(seds)) == (E, Q)
     assert hashlib.sha256(eds).digest() == hashlib.sha256(want_e).digest()
     assert hashlib.sha256(seds).digest() == hashlib.sha256(want_s).digest()
+
+
+def test_two_contexts_download_side_by_side(ctx):
+    """Two contexts of one process, each driven by its own host thread, both with outputs that take the pinned-chunk
+    download (one staging set per device, no process-wide state): same bytes as a single call."""
+    import hashlib
+    import threading
+    import torch
+    import edsparser_amd
+    S, L = 200, 1_200_003
+    n = edsparser_amd.synth_size(S, L)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_synth_device(buf.data_ptr(), n, S, L, seed=7)
+    torch.cuda.synchronize()
+    host = bytes(buf.cpu().numpy())
+    want = ctx.msa_transform(host, 0)
+    assert len(want[1]) >= 16 << 20
+    others = [edsparser_amd.Context(0), edsparser_amd.Context(0)]
+    got = [None, None]
+
+    def work(i):
+        got[i] = others[i].msa_transform(host, 0)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g in got:
+        assert g is not None and hashlib.sha256(g[0]).digest() == hashlib.sha256(want[0]).digest()
+        assert hashlib.sha256(g[1]).digest() == hashlib.sha256(want[1]).digest()
+    for c in others:
+        c.close()
 
 
 def _same_as_oracle(ctx, msa, l):
