@@ -2680,7 +2680,22 @@ int MsaPipeline::get_timing(const char** names, float* ms, int* counts, int cap)
 
 #define TIMED(name, st, ...) do { launch_timer_begin(name, st); __VA_ARGS__; launch_timer_end(st); } while (0)
 
-MsaPipeline::~MsaPipeline() { clear_timers(); }
+MsaPipeline::~MsaPipeline()
+{
+    clear_timers();
+    if (side_ready_) {
+        for (auto& x : side_) (void)hipStreamDestroy(x);
+        for (auto& e : side_ev_) (void)hipEventDestroy(e);
+    }
+}
+
+void MsaPipeline::ensure_side_streams()
+{
+    if (side_ready_) return;
+    for (auto& x : side_) EDSX_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    for (auto& e : side_ev_) EDSX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    side_ready_ = true;
+}
 
 static const char* status_message(u64 st)
 {
@@ -3070,13 +3085,37 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
                                                dim3(256), 0, st, fp));
         };
         launch_emit(k_emit_fast2, "k_emit_fast");
-        TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
-        if (h_.S >= 1000) launch_emit(k_emit_fast<true, true>, "k_emit_fast_wide");      // ids of five bytes exist
-        else launch_emit(k_emit_fast<false, true>, "k_emit_fast_wide");
+        // The small emitters behind it are latency-bound (a few hundred workgroups each, dependent loads): they run
+        // side by side on streams of their own and join the caller's stream at the end.
+        static int side_env = -1;
+        if (side_env < 0) { const char* e = getenv("EDSX_SIDE"); side_env = e ? atoi(e) : 1; }
+        hipStream_t s1 = st, s2 = st;
+        if (side_env) {
+            ensure_side_streams();
+            s1 = side_[0]; s2 = side_[1];
+            EDSX_HIP(hipEventRecord(side_ev_[0], st));
+            EDSX_HIP(hipStreamWaitEvent(s1, side_ev_[0], 0));
+            EDSX_HIP(hipStreamWaitEvent(s2, side_ev_[0], 0));
+        }
+        TIMED("k_emit_common", s1, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, s1, ep));
+        {
+            auto launch_wide = [&](auto kern) {
+                TIMED("k_emit_fast_wide", st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
+                                                                 dim3(256), 0, st, fp));
+            };
+            if (h_.S >= 1000) launch_wide(k_emit_fast<true, true>);      // ids of five bytes exist
+            else launch_wide(k_emit_fast<false, true>);
+        }
         ep.list = fp_.slow_list; ep.list_n = fp_.slow_count;
-        TIMED("k_emit_variant_slow", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+        TIMED("k_emit_variant_slow", s2, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
         ep.list = fp_.slow_list2; ep.list_n = fp_.slow_count2;
-        TIMED("k_emit_variant_slow2", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+        TIMED("k_emit_variant_slow2", s2, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
+        if (side_env) {
+            EDSX_HIP(hipEventRecord(side_ev_[1], s1));
+            EDSX_HIP(hipEventRecord(side_ev_[2], s2));
+            EDSX_HIP(hipStreamWaitEvent(st, side_ev_[1], 0));
+            EDSX_HIP(hipStreamWaitEvent(st, side_ev_[2], 0));
+        }
     } else {
         TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
         TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));

@@ -188,6 +188,11 @@ private:
     u32 recf_stride_ = 0, recf_gid_ = 0;
     FastParams fp_{};
     int cus_ = 0;
+    // side streams of emit(): the small emitters run next to each other
+    hipStream_t side_[2] = {nullptr, nullptr};
+    hipEvent_t side_ev_[3] = {nullptr, nullptr, nullptr};
+    bool side_ready_ = false;
+    void ensure_side_streams();
 };
 
 } // namespace edsx

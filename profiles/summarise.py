@@ -45,3 +45,26 @@ out += ["", "k_scan_extract: algorithmic bytes = 1000 x 1e8 cells = 100.0 GB rea
 open(os.path.join(root, "profiles", "%s_pmc_hbm.md" % tag), "w").write("\n".join(out) + "\n")
 json.dump({"1000x100000000": dict(tj, source="profiles/%s_pmc_hbm.md" % tag)}, open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1)
 print("\n".join(out))
+
+# ---- SQ wave counters (where the waves of each kernel spend their time)
+sqp = os.path.join(go, "pmc_%s_sq" % tag, "p_counter_collection.csv")
+if os.path.exists(sqp):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(sqp)):
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('edsx::', '')
+        acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+    o2 = ["# SQ wave counters per kernel (build %s, 1000 x 100 Mb workload, summed over the launches of one bench run)" % tag, "",
+          "`rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU",
+          "SQ_INSTS_VALU SQ_ACTIVE_INST_LDS` (a pass of its own).  WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = ready but not",
+          "issued, ACTIVE_INST_ANY = issuing; the three add up to WAVE_CYCLES (quad-cycle units).", "",
+          "| kernel | wave cycles | parked (WAIT_ANY) | issue stall (WAIT_INST_ANY) | issuing (ACTIVE_INST_ANY) | of it VALU | of it LDS | VALU instructions |",
+          "|---|---|---|---|---|---|---|---|"]
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+        wc = v.get("SQ_WAVE_CYCLES", 0)
+        if wc < 1e8 or k.startswith("k_synth"):
+            continue
+        pc = lambda n: "%.0f %%" % (100.0 * v.get(n, 0) / wc)
+        o2.append("| %s | %.3g | %s | %s | %s | %s | %s | %.3g |" % (k, wc, pc("SQ_WAIT_ANY"), pc("SQ_WAIT_INST_ANY"), pc("SQ_ACTIVE_INST_ANY"),
+                                                                  pc("SQ_ACTIVE_INST_VALU"), pc("SQ_ACTIVE_INST_LDS"), v.get("SQ_INSTS_VALU", 0)))
+    open(os.path.join(root, "profiles", "%s_pmc_sq.md" % tag), "w").write("\n".join(o2) + "\n")
+    print("\n".join(o2))

@@ -129,3 +129,36 @@ def test_edsparser_stats_cli_gpu(tmp_path):
     (tmp_path / "bad.eds").write_bytes(b"{A,C}{G")
     r = subprocess.run([exe, "-i", str(tmp_path / "bad.eds")], capture_output=True, text=True)
     assert r.returncode == 1 and "Error: Expected '}'" in r.stderr
+
+
+def test_cmake_package_cpu(tmp_path):
+    """The installed CMake package: find_package(EDSParser) + EDSParser::EDSParser, as a user of the reference writes it
+    (README "target_link_libraries(your_target EDSParser::EDSParser)"); the consumer only touches the host container."""
+    import shutil
+    if not shutil.which("cmake"):
+        pytest.skip("cmake not installed")
+    _build_host()
+    b, prefix = tmp_path / "b", tmp_path / "prefix"
+    for cmd in (["cmake", "-S", HOST, "-B", str(b), "-DCMAKE_INSTALL_PREFIX=" + str(prefix)],
+                ["cmake", "--build", str(b), "-j4"], ["cmake", "--install", str(b)]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    for f in ("lib/libedsparser_lib.a", "lib/libedsx.so", "lib/cmake/EDSParser/EDSParserConfig.cmake", "bin/msa2eds",
+              "bin/edsparser-stats", "include/edsparser/transforms/msa_transforms.hpp", "include/edsx.h"):
+        assert (prefix / f).exists(), f
+    user = tmp_path / "user"
+    user.mkdir()
+    (user / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.16)\nproject(user CXX)\nfind_package(EDSParser REQUIRED)\n"
+        "add_executable(user main.cpp)\ntarget_link_libraries(user EDSParser::EDSParser)\n")
+    (user / "main.cpp").write_text(
+        '#include "edsparser/formats/eds.hpp"\n#include "edsparser/transforms/eds_transforms.hpp"\n'
+        'int main() { edsparser::EDS e(std::string("{ACGT}{A,C}{GTTT}")); '
+        'return (e.length() == 3 && e.cardinality() == 4 && edsparser::is_leds(e, 4)) ? 0 : 1; }\n')
+    for cmd in (["cmake", "-S", str(user), "-B", str(user / "b"), "-DCMAKE_PREFIX_PATH=" + str(prefix)],
+                ["cmake", "--build", str(user / "b")]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    env = dict(os.environ, LD_LIBRARY_PATH=str(prefix / "lib") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([str(user / "b" / "user")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
