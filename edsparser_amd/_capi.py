@@ -79,6 +79,9 @@ def load_library():
                                        ctypes.c_size_t, ctypes.c_uint32, P(_Buf), P(_Buf), P(VcfStats)]
     lib.edsx_eds_stats.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
                                    ctypes.c_uint32, P(EdsStatistics)]
+    lib.edsx_genrandomeds.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_uint32, ctypes.c_uint32,
+                                      ctypes.c_uint32, ctypes.c_double, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64,
+                                      P(_Buf), P(_Buf), P(ctypes.c_uint64)]
     lib.edsx_leds_tokenised_on_device.argtypes = [ctypes.c_void_p]
     lib.edsx_vcf_tokenised_on_device.argtypes = [ctypes.c_void_p]
     lib.edsx_leds_merge_range.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
@@ -167,6 +170,16 @@ class Context:
         self._check(self._lib.edsx_eds_stats(self._h, eds, len(eds), seds, len(seds) if seds is not None else 0,
                                              context_len, ctypes.byref(st)))
         return {n: getattr(st, n) for n, _ in EdsStatistics._fields_}
+
+    def genrandomeds(self, total_bp, variability=0.10, min_alt=2, max_alt=4, var_len_max=10, snp_ratio=0.7,
+                     alphabet="ACGT", min_context=0, seed=42):
+        """genrandomeds-shaped (.eds, .seds, number of variant sites), generated on the GPU."""
+        e, s = _Buf(), _Buf()
+        n = ctypes.c_uint64(0)
+        self._check(self._lib.edsx_genrandomeds(self._h, total_bp, variability, min_alt, max_alt, var_len_max, snp_ratio,
+                                                alphabet.encode(), min_context, seed, ctypes.byref(e), ctypes.byref(s),
+                                                ctypes.byref(n)))
+        return self._take(e), self._take(s), n.value
 
     def vcf_transform(self, vcf, fasta, context_len=0):
         e, s, st = _Buf(), _Buf(), VcfStats()

@@ -1,6 +1,7 @@
 // capi.hip — the extern "C" boundary declared in include/edsx.h.  No exceptions cross it.
 #include "../../include/edsx.h"
 
+#include "genrandom.hpp"
 #include "merge_device.hpp"
 #include "msa_device.hpp"
 #include "synth.hpp"
@@ -20,6 +21,7 @@ struct edsx_ctx {
     MsaPipeline msa;
     MergePipeline merge;
     VcfPipeline vcf;
+    GenPipeline gen;
     DevBuf d_in, d_eds, d_seds, synth_desc;
 };
 
@@ -329,6 +331,30 @@ int edsx_vcf_transform_range(edsx_ctx* ctx, const uint8_t* vcf, size_t vcf_size,
             stats->skipped_malformed = c.skipped_malformed; stats->skipped_unsupported_sv = c.skipped_unsupported_sv;
             stats->variant_groups = c.variant_groups;
         }
+        eds->size = e.size; eds->data = e.release();
+        seds->size = s.size; seds->data = s.release();
+    });
+}
+
+int edsx_genrandomeds(edsx_ctx* ctx, uint64_t total_bp, double variability, uint32_t min_alt, uint32_t max_alt,
+                      uint32_t var_len_max, double snp_ratio, const char* alphabet, uint64_t min_context, uint64_t seed,
+                      edsx_buf* eds, edsx_buf* seds, uint64_t* n_sites)
+{
+    if (eds) { eds->data = nullptr; eds->size = 0; }
+    if (seds) { seds->data = nullptr; seds->size = 0; }
+    return guarded(ctx, [&] {
+        if (!eds || !seds || !alphabet) throw ParamError("null argument");
+        GenParams gp{};
+        gp.total_bp = total_bp; gp.variability = variability; gp.min_alt = min_alt; gp.max_alt = max_alt;
+        gp.var_len_max = var_len_max; gp.snp_ratio = snp_ratio; gp.min_context = min_context; gp.seed = seed;
+        const size_t an = std::strlen(alphabet);
+        if (an > 64) throw ParamError("Alphabet of more than 64 characters is not supported by this build");
+        gp.alpha_n = (u32)an;
+        std::memcpy(gp.alphabet, alphabet, an);
+        HostBytes e, s;
+        u64 sites = 0;
+        ctx->gen.run(gp, e, s, sites, nullptr);
+        if (n_sites) *n_sites = sites;
         eds->size = e.size; eds->data = e.release();
         seds->size = s.size; seds->data = s.release();
     });

@@ -140,6 +140,16 @@ typedef struct {
 int edsx_eds_stats(edsx_ctx* ctx, const uint8_t* eds, size_t eds_size, const uint8_t* seds, size_t seds_size,
                    uint32_t context_len, edsx_eds_statistics* out);
 
+/* ---- synthetic inputs: genrandomeds-shaped .eds + .seds generated in HBM ----
+ * Flags and shape of src/cpp/tools/genrandomeds.cpp:383-405 / :221-352 (reference uniform over `alphabet`, single-position
+ * variant sites with min_alt..max_alt alternatives, snp_ratio SNPs, else insertions of 1..var_len_max characters /
+ * deletions, max(max_alt, 3) paths, {0} for common blocks, FULL brackets, no trailing newline).  Counter-based, not the
+ * reference's mt19937 stream: the same (seed, flags) always give the same text, but not the reference's bytes; with
+ * min_context == 0 the number of sites is binomial around total_bp * variability instead of exactly its floor. */
+int edsx_genrandomeds(edsx_ctx* ctx, uint64_t total_bp, double variability, uint32_t min_alt, uint32_t max_alt,
+                      uint32_t var_len_max, double snp_ratio, const char* alphabet, uint64_t min_context, uint64_t seed,
+                      edsx_buf* eds, edsx_buf* seds, uint64_t* n_sites);
+
 /* ---- device-resident MSA path (inputs/outputs stay in HBM) ---- */
 
 /* Phase 1: index rows, scan columns, build the segment table and size the outputs.
