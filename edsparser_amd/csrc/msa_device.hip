@@ -2823,7 +2823,11 @@ void MsaPipeline::plan_body(hipStream_t st)
     const bool hold = (u64)RPT * (T >> cpr_log2) >= S;
     const u64 W = 16ull << cpr_log2;
     const u64 ntiles = (Draw + W - 1) / W;
-    const size_t colbuf_bytes = cfg == 0 ? 96 * 1024 : 64 * 1024;
+    static int cb_env = -1;
+    if (cb_env < 0) { const char* e = getenv("EDSX_K1_LDS"); cb_env = e ? atoi(e) : 0; }
+    // 40 KB of column image (39 columns of 1000 rows; denser tiles take the batched path) leave room for a third
+    // workgroup per CU to start while the two resident ones finish their grouping tails (-1.7 % on the scan)
+    const size_t colbuf_bytes = cb_env ? (size_t)cb_env * 1024 : cfg == 0 ? 96 * 1024 : ((size_t)S * 8 <= 40 * 1024 ? 40 * 1024 : 64 * 1024);
     if (ntiles > 0x7fffffffull) throw FormatError("MSA too large for one launch");
     if (colbuf_bytes < (size_t)S * 8) throw LimitError(status_message(ST_TOO_MANY_ROWS));
 
