@@ -124,6 +124,43 @@ def piece_bounds(edges, action):
     return e_lo, e_hi, s_lo, s_hi
 
 
+class TensorComm:
+    """The exchanges of the partitions as tensor collectives (no pickled objects): all_gather_into_tensor of int64
+    vectors of a fixed length, and of uint8 payloads padded to the largest contribution (their sizes travel first).
+    `device` is where the collective's tensors live ("cuda" for nccl = RCCL, "cpu" for gloo)."""
+
+    def __init__(self, dist, world, device=None):
+        self.dist, self.world, self.device = dist, world, device
+
+    def _dev(self):
+        if self.device is None:
+            self.device = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        return self.device
+
+    def _gather(self, t):
+        import torch
+        out = torch.empty((self.world, t.numel()), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out.view(-1), t.contiguous())
+        return out.cpu()
+
+    def ints(self, values):
+        """Every rank contributes the same number of integers -> list (by rank) of lists."""
+        import torch
+        g = self._gather(torch.tensor([int(v) for v in values], dtype=torch.int64, device=self._dev()))
+        return [[int(x) for x in g[r].tolist()] for r in range(self.world)]
+
+    def payloads(self, data):
+        """bytes of any length per rank -> list (by rank) of bytes."""
+        import torch
+        sizes = [v[0] for v in self.ints([len(data)])]
+        cap = max(max(sizes), 1)
+        buf = torch.zeros(cap, dtype=torch.uint8)
+        if len(data):
+            buf[:len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        g = self._gather(buf.to(self._dev()))
+        return [g[r, :sizes[r]].numpy().tobytes() for r in range(self.world)]
+
+
 EDGE_FIELDS = ("n_segments", "cols", "eds_bytes", "seds_bytes", "first_is_variant", "first_cols", "first_eds_bytes",
                "first_seds_bytes", "last_is_variant", "last_cols", "last_eds_bytes", "last_seds_bytes")
 
@@ -455,11 +492,12 @@ def _line_runs(g_sel, k, base, off, length, vcf, lo):
 
 class VcfSharder:
     """Runs the position-range partition for one rank.  `dist` is torch.distributed (nccl = RCCL on the GPU
-    box, gloo in the CPU tests); only all_gather_object is used.  The three callables are the C ABI on the
+    box, gloo in the CPU tests); every exchange is a tensor collective (TensorComm).  The three callables are the C ABI on the
     GPU (gpu_vcf_sharder) and the oracle in the CPU tests."""
 
-    def __init__(self, rank, world, dist, index_fn, sort_fn, range_fn):
+    def __init__(self, rank, world, dist, index_fn, sort_fn, range_fn, device=None):
         self.rank, self.world, self.dist = rank, world, dist
+        self.comm = TensorComm(dist, world, device)
         self.index_fn = index_fn            # bytes -> (pos, reflen, line_off, line_len, counters)
         self.sort_fn = sort_fn              # uint64[n] -> uint32[n]
         self.range_fn = range_fn            # (lines, fasta, cur0, next_start|None) -> (eds, seds, counters)
@@ -470,8 +508,15 @@ class VcfSharder:
         rank, world = self.rank, self.world
         lo, hi = vcf_byte_range(vcf, rank, world)
         pos, reflen, off, length, counters = self.index_fn(vcf[lo:hi])
-        gathered = [None] * world
-        self.dist.all_gather_object(gathered, (pos, reflen, counters))
+        # (POS, REF length) of every record, 16 bytes each, and the four counters: tensor collectives
+        CK = ("total_variants", "processed_variants", "skipped_malformed", "skipped_unsupported_sv")
+        head = self.comm.ints([len(pos)] + [counters[k] for k in CK])
+        blobs = self.comm.payloads(np.concatenate((np.asarray(pos, dtype=np.uint64), np.asarray(reflen, dtype=np.uint64))).tobytes())
+        gathered = []
+        for r in range(world):
+            arr = np.frombuffer(blobs[r], dtype=np.uint64)
+            nr = head[r][0]
+            gathered.append((arr[:nr], arr[nr:2 * nr], dict(zip(CK, head[r][1:]))))
         base = np.concatenate(([0], np.cumsum([len(g[0]) for g in gathered]))).astype(np.int64)
         gpos = np.concatenate([g[0] for g in gathered]).astype(np.uint64)
         greflen = np.concatenate([g[1] for g in gathered]).astype(np.uint64)
@@ -496,10 +541,31 @@ class VcfSharder:
                 mine = runs
             else:
                 outgoing[d] = runs
-        everything = [None] * world
-        self.dist.all_gather_object(everything, outgoing)
-        sources = ([mine] if mine is not None else []) + [everything[r][rank] for r in range(world)
-                                                         if r != rank and rank in everything[r]]
+        # record lines that change rank: per destination (run count, blob bytes) as integers, then one byte payload per
+        # rank = for every destination in order its run_k (int64), run_nbytes (int64) and text
+        hdr, parts = [], []
+        for d in range(world):
+            if d in outgoing:
+                rk, rn, blob = outgoing[d]
+                hdr += [len(rk), len(blob)]
+                parts += [np.asarray(rk, dtype=np.int64).tobytes(), np.asarray(rn, dtype=np.int64).tobytes(), blob]
+            else:
+                hdr += [0, 0]
+        heads = self.comm.ints(hdr)
+        pay = self.comm.payloads(b"".join(parts))
+        incoming = []
+        for r in range(world):
+            if r == rank:
+                continue
+            at = 0
+            for d in range(world):
+                nr, nb = heads[r][2 * d], heads[r][2 * d + 1]
+                if d == rank and (nr or nb):
+                    rk = np.frombuffer(pay[r], dtype=np.int64, count=nr, offset=at)
+                    rn = np.frombuffer(pay[r], dtype=np.int64, count=nr, offset=at + 8 * nr)
+                    incoming.append((rk, rn, pay[r][at + 16 * nr:at + 16 * nr + nb]))
+                at += 16 * nr + nb
+        sources = ([mine] if mine is not None else []) + incoming
         if not sources:
             lines = b""
         elif len(sources) == 1 and len(sources[0][0]) == 1:
@@ -529,13 +595,11 @@ class VcfSharder:
                 groups = st["variant_groups"]
             except Exception as ex:                                # noqa: BLE001 — re-raised on every rank below
                 err = ex
-        sizes = [None] * world
-        self.dist.all_gather_object(sizes, (len(eds), len(seds), groups, None if err is None else (type(err).__name__, str(err), getattr(err, "code", None))))
-        failed = [s[3] for s in sizes if s[3] is not None]
-        if failed:
+        sizes = self.comm.ints([len(eds), len(seds), groups, 0 if err is None else 1])
+        if any(s[3] for s in sizes):
             if err is not None:
-                raise err
-            raise RuntimeError("VCF range transform failed on another rank: %s: %s" % (failed[0][0], failed[0][1]))
+                raise err                                          # the rank that failed words the error
+            raise RuntimeError("VCF range transform failed on rank %d" % [s[3] for s in sizes].index(1))
         stats = {k: sum(g[2][k] for g in gathered) for k in
                  ("total_variants", "processed_variants", "skipped_malformed", "skipped_unsupported_sv")}
         stats["variant_groups"] = sum(s[2] for s in sizes)
@@ -548,10 +612,10 @@ class VcfSharder:
         return self.last
 
 
-def gpu_vcf_sharder(ctx, rank, world, dist):
+def gpu_vcf_sharder(ctx, rank, world, dist, device=None):
     """VcfSharder wired to the C ABI of this rank's GPU context."""
     return VcfSharder(rank, world, dist, ctx.vcf_index, ctx.vcf_sort_order,
-                      lambda lines, fasta, cur0, nxt: ctx.vcf_transform_range(lines, fasta, cur0, nxt))
+                      lambda lines, fasta, cur0, nxt: ctx.vcf_transform_range(lines, fasta, cur0, nxt), device=device)
 
 
 # ======================================================================================================
@@ -568,7 +632,7 @@ def gpu_vcf_sharder(ctx, rank, world, dist):
 # sentinels stayed untouched (edsx_leds_merge_range) and if one did not — or a range fails — rank 0 runs the
 # unpartitioned merge, which also yields the reference's error text with whole-file positions.
 #
-# Exchange steps (all_gather_object of a few integers each):
+# Exchange steps (all_gather_into_tensor of a few int64 each):
 #   1. every rank scans its byte range of .eds / .seds: string starts, '{' of .seds, and the first sentinel at or after
 #      the start of its range (with the number of strings in front of it inside the range),
 #   2. the ranks that hold the sentinels' source sets in .seds locate them (set index = strings in front),
@@ -676,8 +740,9 @@ class MergeSharder:
     """Runs the symbol-range partition of the merge for one rank.  range_fn / whole_fn are the C ABI on the GPU
     (gpu_merge_sharder) and the oracle in the CPU tests."""
 
-    def __init__(self, rank, world, dist, range_fn, whole_fn):
+    def __init__(self, rank, world, dist, range_fn, whole_fn, device=None):
         self.rank, self.world, self.dist = rank, world, dist
+        self.comm = TensorComm(dist, world, device)
         self.range_fn = range_fn    # (eds, seds|None, l, compact, head, tail) -> (leds, seds_out, head_intact, tail_intact)
         self.whole_fn = whole_fn    # (eds, seds|None, l, compact) -> (leds, seds_out)
         self.last = None
@@ -689,12 +754,11 @@ class MergeSharder:
                 out, sout = self.whole_fn(eds, seds, l, compact)
             except Exception as ex:  # noqa: BLE001 — raised on every rank below
                 err = ex
-        sizes = [None] * self.world
-        self.dist.all_gather_object(sizes, (len(out), len(sout), None if err is None else (type(err).__name__, str(err))))
-        if sizes[0][2] is not None:
+        sizes = self.comm.ints([len(out), len(sout), 0 if err is None else 1])
+        if sizes[0][2]:
             if err is not None:
-                raise err
-            raise RuntimeError("merge failed on rank 0: %s: %s" % sizes[0][2])
+                raise err                                          # rank 0 words the reference's error
+            raise RuntimeError("merge failed on rank 0")
         self.last = {"leds": out, "seds": sout, "partitioned": False, "why": why, "ranges": 1,
                      "leds_offset": 0 if self.rank == 0 else sizes[0][0], "seds_offset": 0 if self.rank == 0 else sizes[0][1],
                      "leds_total": sizes[0][0], "seds_total": sizes[0][1]}
@@ -712,8 +776,10 @@ class MergeSharder:
         send = _text_end(seds) if linear else 0
         slo, shi = send * rank // world, send * (rank + 1) // world
         sok, sbraces = seds_scan_range(seds, slo, shi) if linear else (True, 0)
-        g1 = [None] * world
-        self.dist.all_gather_object(g1, (scan["ok"] and sok, scan["strings"], scan["cut"], sbraces))
+        cut = scan["cut"]
+        g1 = [(bool(v[0]), v[1], (v[3], v[4], v[5]) if v[2] else None, v[6]) for v in
+              self.comm.ints([1 if (scan["ok"] and sok) else 0, scan["strings"], 1 if cut is not None else 0] +
+                             (list(cut) if cut is not None else [0, 0, 0]) + [sbraces])]
         if not all(g[0] for g in g1):
             return self._whole_on_rank0(eds, seds, l, compact, "text not partitionable")
         str_base = np.concatenate(([0], np.cumsum([g[1] for g in g1])))
@@ -733,11 +799,14 @@ class MergeSharder:
                 for r in mine:
                     p0 = int(pos[sent[r][2] - int(br_base[rank])]) + slo
                     located[r] = (p0, seds.find(b"}", p0) + 1)
-            g2 = [None] * world
-            self.dist.all_gather_object(g2, located)
+            flat = []
+            for r in range(world):                                  # (start, end) of sentinel r's source set, -1: not mine
+                flat += list(located[r]) if r in located else [-1, -1]
             located = {}
-            for g in g2:
-                located.update(g)
+            for g in self.comm.ints(flat):
+                for r in range(world):
+                    if g[2 * r] >= 0:
+                        located[r] = (g[2 * r], g[2 * r + 1])
             if any(r not in located or located[r][1] <= 0 for r in cut_ranks):
                 return self._whole_on_rank0(eds, seds, l, compact, "source set of a sentinel not found")
         # ---- my range
@@ -759,8 +828,7 @@ class MergeSharder:
                 out, sout, head_ok, tail_ok = self.range_fn(eds[e0:e1], s_slice, l, compact, rank != 0, nxt is not None)
             except Exception as ex:  # noqa: BLE001 — any failure sends the whole text to rank 0 (exact error text)
                 err = ex
-        g3 = [None] * world
-        self.dist.all_gather_object(g3, (len(out), len(sout), head_ok and tail_ok and err is None))
+        g3 = self.comm.ints([len(out), len(sout), 1 if (head_ok and tail_ok and err is None) else 0])
         if not all(g[2] for g in g3):
             return self._whole_on_rank0(eds, seds, l, compact, "a sentinel was merged or a range failed")
         self.last = {"leds": out, "seds": sout, "partitioned": True, "why": "", "ranges": len(owners),

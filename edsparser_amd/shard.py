@@ -64,9 +64,9 @@ def run_vcf2eds(a, rank, world, dist, vcf_sharder, merge_sharder):
     if a.context_length > 0:
         # vcf_transforms.cpp:735-755: the EDS text goes through the LINEAR merge (compact).  The merge partition
         # scans byte ranges of the whole text, so the pieces are gathered first.
-        pieces = [None] * world
-        dist.all_gather_object(pieces, (eds, seds))
-        m = merge_sharder.run(b"".join(p[0] for p in pieces), b"".join(p[1] for p in pieces), a.context_length, True)
+        comm = mg.TensorComm(dist, world)
+        all_eds, all_seds = comm.payloads(eds), comm.payloads(seds)
+        m = merge_sharder.run(b"".join(all_eds), b"".join(all_seds), a.context_length, True)
         eds, seds = m["leds"], m["seds"]
         e_off, e_tot, s_off, s_tot = m["leds_offset"], m["leds_total"], m["seds_offset"], m["seds_total"]
     write_piece(eds_path, eds, e_off, e_tot, rank, dist)
