@@ -2,7 +2,9 @@
 // Flags, defaults, file naming and messages follow the reference tool
 // (src/cpp/tools/msa2eds.cpp:35-41, :92-97, :139-160, :116-120, :178-180).
 #include "edsparser/transforms/msa_transforms.hpp"
+#include "edsx.h"
 #include "../cli_util.hpp"
+#include "../device.hpp"
 #include "tool_common.hpp"
 
 using namespace edsparser;
@@ -46,16 +48,19 @@ int main(int argc, char** argv)
             tool::print_performance(timer);
             return 1;
         }
-        std::ifstream msa_in(input_file);
-        if (!msa_in) throw std::runtime_error("Failed to open input file: " + input_file.string());
+        // the file is mapped and handed to the C ABI as it is (what parse_msa_to_*_streaming does with a stream, minus
+        // the copy into a std::string in front of the host-to-device copy)
+        tool::MappedFile msa_in(input_file, "input");
 
         const bool create_leds = context_length > 0;
         if (create_leds) std::cout << "MSA → l-EDS transformation (l=" << context_length << ")\n";
         else std::cout << "MSA → EDS transformation\n";
         std::cout << "  Input: " << input_file << "\n";
 
-        auto result = create_leds ? parse_msa_to_leds_streaming(msa_in, context_length) : parse_msa_to_eds_streaming(msa_in);
-        msa_in.close();
+        edsx_ctx* ctx = detail::context();
+        detail::Buf eds_out, seds_out;
+        const int rc = edsx_msa_transform(ctx, msa_in.data(), msa_in.size(), context_length, &eds_out.b, &seds_out.b);
+        if (rc != EDSX_OK) detail::throw_status(rc, ctx);
 
         std::filesystem::path eds_path, seds_path;
         if (create_leds) {
@@ -66,8 +71,8 @@ int main(int argc, char** argv)
             eds_path = output_file.empty() ? input_file.parent_path() / (input_file.stem().string() + ".eds") : output_file;
             seds_path = sources_file.empty() ? eds_path.parent_path() / (eds_path.stem().string() + ".seds") : sources_file;
         }
-        tool::write_file(eds_path, result.first, "output");
-        tool::write_file(seds_path, result.second, "sources");
+        tool::write_bytes(eds_path, eds_out.b.data, eds_out.b.size, "output");
+        tool::write_bytes(seds_path, seds_out.b.data, seds_out.b.size, "sources");
 
         std::cout << "Transformation complete!\n";
         std::cout << "  Output: " << eds_path << "\n";

@@ -2,7 +2,9 @@
 // Flags, validation, naming, statistics block: src/cpp/tools/vcf2eds.cpp:36-43, :102-114,
 // :159-180, :204-216.
 #include "edsparser/transforms/vcf_transforms.hpp"
+#include "edsx.h"
 #include "../cli_util.hpp"
+#include "../device.hpp"
 #include "tool_common.hpp"
 
 using namespace edsparser;
@@ -49,10 +51,8 @@ int main(int argc, char** argv)
             tool::print_performance(timer);
             return 1;
         }
-        std::ifstream vcf_in(input_file);
-        if (!vcf_in) throw std::runtime_error("Failed to open VCF file: " + input_file.string());
-        std::ifstream fasta_in(reference_file);
-        if (!fasta_in) throw std::runtime_error("Failed to open reference FASTA file: " + reference_file.string());
+        // both files are mapped and handed to the C ABI as they are (no ifstream -> std::string copies)
+        tool::MappedFile vcf_in(input_file, "VCF"), fasta_in(reference_file, "reference FASTA");
 
         const bool create_leds = context_length > 0;
         if (create_leds) {
@@ -65,10 +65,15 @@ int main(int argc, char** argv)
         std::cout << "  Reference: " << reference_file << "\n";
 
         VCFStats stats;
-        auto result = create_leds ? parse_vcf_to_leds_streaming(vcf_in, fasta_in, context_length, &stats)
-                                  : parse_vcf_to_eds_streaming(vcf_in, fasta_in, &stats);
-        vcf_in.close();
-        fasta_in.close();
+        edsx_ctx* ctx = detail::context();
+        detail::Buf eds_out, seds_out;
+        edsx_vcf_stats cst{};
+        const int rc = edsx_vcf_transform(ctx, vcf_in.data(), vcf_in.size(), fasta_in.data(), fasta_in.size(), context_length,
+                                          &eds_out.b, &seds_out.b, &cst);
+        stats.total_variants = cst.total_variants; stats.processed_variants = cst.processed_variants;
+        stats.skipped_malformed = cst.skipped_malformed; stats.skipped_unsupported_sv = cst.skipped_unsupported_sv;
+        stats.variant_groups = cst.variant_groups;
+        if (rc != EDSX_OK) detail::throw_status(rc, ctx);
 
         std::filesystem::path eds_path, seds_path;
         if (create_leds) {
@@ -79,8 +84,8 @@ int main(int argc, char** argv)
             eds_path = output_file.empty() ? input_file.parent_path() / (input_file.stem().string() + ".eds") : output_file;
             seds_path = sources_file.empty() ? eds_path.parent_path() / (eds_path.stem().string() + ".seds") : sources_file;
         }
-        tool::write_file(eds_path, result.first, "output");
-        tool::write_file(seds_path, result.second, "sources");
+        tool::write_bytes(eds_path, eds_out.b.data, eds_out.b.size, "output");
+        tool::write_bytes(seds_path, seds_out.b.data, seds_out.b.size, "sources");
 
         std::cout << "Transformation complete!\n";
         std::cout << "  Output: " << eds_path << "\n";
