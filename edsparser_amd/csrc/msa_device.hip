@@ -909,24 +909,23 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
             }
             // ---- the runs of variant columns that lie inside the tile and are at most FUSE_MAXW wide are grouped here
             // (registered by the thread that owns their first column); every other variant column goes to vc
-            if (tid < cpr && !(p.dbg & 256u)) {
-                const u32 m = D[tid];
-                // window: previous, own and the next two chunks.  Beyond the tile the runs may go on: all ones there
-                const u64 w = (tid ? (u64)D[tid - 1] : 0xffffull) | ((u64)m << 16) | ((u64)(tid + 1 < cpr ? D[tid + 1] : 0xffffu) << 32) |
-                              ((u64)(tid + 2 < cpr ? D[tid + 2] : 0xffffu) << 48);
-                const u32 idxb = pre_of(tid);
-                u32 cs = 0;
-                for (u32 mm = m; mm; mm &= mm - 1) {
-                    const u32 b = (u32)__builtin_ctz(mm), pp = 16u + b;
+            if (!(p.dbg & 256u))
+            for (u32 col = tid; col < cpr * 16u; col += T) {   // one thread per column of the tile
+                const u32 ch = col >> 4, b = col & 15u;
+                const u32 m = D[ch];
+                if ((m >> b) & 1u) {
+                    // window: previous, own and the next two chunks.  Beyond the tile the runs may go on: all ones there
+                    const u64 w = (ch ? (u64)D[ch - 1] : 0xffffull) | ((u64)m << 16) | ((u64)(ch + 1 < cpr ? D[ch + 1] : 0xffffu) << 32) |
+                                  ((u64)(ch + 2 < cpr ? D[ch + 2] : 0xffffu) << 48);
+                    const u32 pp = 16u + b;
                     const u32 up = (u32)__builtin_ctzll(~(w >> pp));                 // ones from this column upwards
                     const u32 dn = (u32)__builtin_clzll(~(w << (64u - pp)));         // ones below it
-                    const u32 idx = idxb + (u32)__builtin_popcount(m & ((1u << b) - 1u));
+                    const u32 idx = pre_of(ch) + (u32)__builtin_popcount(m & ((1u << b) - 1u));
                     // (a run that reaches the bottom of the window may be longer than it looks: not for this path.
                     // Upwards the window shows at least 32 columns, so the thread of a run's first column sees it whole.)
                     if (up + dn > FUSE_MAXW || dn == pp) clist[CLIST - 1u - atomicAdd(&nst_sh, 1u)] = (uint16_t)idx;
-                    else if (dn == 0) { clist[atomicAdd(&ncand_sh, 1u)] = (uint16_t)(idx | ((up + dn) << 11)); cs |= 1u << b; }
+                    else if (dn == 0) { clist[atomicAdd(&ncand_sh, 1u)] = (uint16_t)(idx | ((up + dn) << 11)); atomicOr(&CS[ch], 1u << b); }
                 }
-                CS[tid] = cs;
             }
             if (tid == 0) {                                    // first use of the atomic's result
                 slot_base_sh = base_r;
