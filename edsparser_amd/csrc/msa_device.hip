@@ -646,20 +646,60 @@ __device__ __forceinline__ uint2 pack_gid4(const uint4& gid, const uint4& vmask)
 // (msa_transforms.cpp:262-293).  desc = index of the run's first column in colbuf | width << 11.  Writes the fused
 // record (group ids + .eds text) and rec_info, or - when the run is not for this path (another alphabet, more than
 // 16 strings, a long text) - copies its columns to vc for the grouping kernels.
+// ROWS64 (S <= 64): one row per lane instead of sixteen - a column is one byte per lane, the distinct strings fall out
+// of a ballot per string, and runs of up to 20 columns are taken (exact 3-bit keys of the gap-stripped strings, ten
+// letters per dword).
+template <bool ROWS64>
 __device__ __forceinline__ void fused_group_run(const K1Params& p, const uint8_t* colbuf, u32 desc, u64 slot_base, u32 lane,
                                                 const uint4& vmask, u32 nl, u32 loff)
 {
     const u32 idx0 = desc & 0x7ffu, w = desc >> 11;
     const uint8_t* c0p = colbuf + (size_t)idx0 * p.Spad;
-    const uint4 col0 = *reinterpret_cast<const uint4*>(c0p + loff);
     FastGroups G;
     G.gid = make_uint4(~0u, ~0u, ~0u, ~0u);
     G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
     bool ok;
+    if constexpr (ROWS64) {
+        const bool act = lane < p.S;
+        const u64 LET = ((u64)DNA_LET_HI << 32) | DNA_LET_LO;
+        u32 klo = 0, khi = 0, len = 0, bad = 0;
+        for (u32 c = 0; c < w; c++) {                          // the gap-stripped string of row `lane` as class codes
+            const u32 ch = act ? (u32)c0p[(size_t)c * p.Spad + lane] : (u32)'-';
+            const u32 cls = ((ch >> 1) ^ (ch >> 2)) & 7u;
+            bad |= ((u32)(LET >> (8u * cls)) & 0xffu) != ch ? 1u : 0u;
+            if (cls != 5u) { if (len < 10u) klo |= cls << (3u * len); else khi |= cls << (3u * (len - 10u)); len++; }
+        }
+        ok = !ballot64(act && bad);
+        u32 mygid = 0, gk_lo = 0, gk_hi = 0, glen = 0;         // lane g: string g
+        if (ok) {
+            u64 todo = ballot64(act);
+            while (todo) {                                     // strings in the order of their first rows (msa_transforms.cpp:288-293)
+                const int leader = __builtin_ctzll(todo);
+                const u32 a0 = (u32)__builtin_amdgcn_readlane((int)klo, leader), a1 = (u32)__builtin_amdgcn_readlane((int)khi, leader);
+                const u32 l0 = (u32)__builtin_amdgcn_readlane((int)len, leader);
+                const u64 m = ballot64(act && klo == a0 && khi == a1 && len == l0);
+                if ((m >> lane) & 1ull) mygid = G.k;
+                if (lane == G.k) { gk_lo = a0; gk_hi = a1; glen = l0; }
+                G.k++; G.sumlen += l0;
+                todo &= ~m;
+            }
+            G.key_lo = ((u64)gk_hi << 32) | gk_lo; G.len = glen;
+            // group-id bytes of rows 16l .. 16l+15 for the lanes that own a dword of the record
+            uint32_t gb[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const u32 v = (u32)__shfl((int)mygid, (int)((lane * 16u + (u32)i) & 63u), 64);
+                gb[i >> 2] |= (v & 0xffu) << ((i & 3) * 8);
+            }
+            G.gid = make_uint4(gb[0], gb[1], gb[2], gb[3]);
+        }
+    } else {
+    const uint4 col0 = *reinterpret_cast<const uint4*>(c0p + loff);
     if (w == 1u) ok = fast_group_dna1(col0, lane < p.S ? (u32)c0p[lane] : 0u, vmask, lane, p.S, G);
     else {
         auto load_col = [&](u32 c) -> uint4 { return *reinterpret_cast<const uint4*>(c0p + (size_t)c * p.Spad + loff); };
         ok = fast_group_dnakeys<1>(load_col, w, col0, lane, vmask, G) > 0;
+    }
     }
     const u32 textlen = 1u + G.k + G.sumlen;             // "{" + strings + separators / "}"
     ok = ok && G.k <= 16u && textlen <= REC_TEXT_MAX;
@@ -673,7 +713,7 @@ __device__ __forceinline__ void fused_group_run(const K1Params& p, const uint8_t
             else *reinterpret_cast<uint2*>(rec + lane * 8u) = pack_gid4(G.gid, vmask);
         }
         uint8_t* t = rec + p.recf_gid + 4;
-        if (w == 1u) {                             // lane g holds string g's letter (0: the empty string)
+        if (w == 1u && !ROWS64) {                  // lane g holds string g's letter (0: the empty string)
             const u32 c = lane < G.k ? (u32)G.key_lo : 0u;
             const u64 nz = ballot64(c != 0);
             const u32 at = 1u + lane + mbcnt(nz);
@@ -706,7 +746,7 @@ __device__ __forceinline__ void fused_group_run(const K1Params& p, const uint8_t
     }
 }
 
-template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW>
+template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW, bool ROWS64 = false>
 __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t colbuf[];
@@ -923,7 +963,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                     const u32 idx = pre_of(ch) + (u32)__builtin_popcount(m & ((1u << b) - 1u));
                     // (a run that reaches the bottom of the window may be longer than it looks: not for this path.
                     // Upwards the window shows at least 32 columns, so the thread of a run's first column sees it whole.)
-                    if (up + dn > FUSE_MAXW || dn == pp) clist[CLIST - 1u - atomicAdd(&nst_sh, 1u)] = (uint16_t)idx;
+                    if (up + dn > (ROWS64 ? 20u : FUSE_MAXW) || dn == pp) clist[CLIST - 1u - atomicAdd(&nst_sh, 1u)] = (uint16_t)idx;
                     else if (dn == 0) { clist[atomicAdd(&ncand_sh, 1u)] = (uint16_t)(idx | ((up + dn) << 11)); atomicOr(&CS[ch], 1u << b); }
                 }
             }
@@ -966,7 +1006,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                 const uint4 vmask = fast_valid_mask(lane, p.S);
                 const u32 loff = lane * 16u < p.Spad - 16u ? lane * 16u : p.Spad - 16u;
                 for (u32 ci = uniform32(tid >> 6); ci < ncand; ci += T / 64)
-                    fused_group_run(p, colbuf, uniform32((u32)clist[ci]), slot_base, lane, vmask, nl, loff);
+                    fused_group_run<ROWS64>(p, colbuf, uniform32((u32)clist[ci]), slot_base, lane, vmask, nl, loff);
             }
         } } else
         for (u32 b0 = 0; b0 < nv || b0 == 0; b0 += cap) {
@@ -2706,10 +2746,10 @@ static const char* status_message(u64 st)
     return "MSA transform failed";
 }
 
-template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW>
+template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW, bool ROWS64 = false>
 static void launch_k1(const K1Params& p, size_t lds, hipStream_t st)
 {
-    auto kern = k_scan_extract<T, RPT, HOLD, LANEROWS, MINW>;
+    auto kern = k_scan_extract<T, RPT, HOLD, LANEROWS, MINW, ROWS64>;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)p.ntiles), dim3(T), lds, st, p);
@@ -2854,7 +2894,8 @@ void MsaPipeline::plan_body(hipStream_t st)
     }
     launch_timer_begin("k_scan_extract", st);
     if (cfg == 1) {
-        if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
+        if (lane_rows && fuse_ && S <= 64) launch_k1<512, 16, true, true, 4, true>(kp, colbuf_bytes, st);   // one row per lane in the fused grouping
+        else if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
         else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
         else launch_k1<512, 16, false, false, 4>(kp, colbuf_bytes, st);
     } else if (cfg == 2) {
