@@ -3043,31 +3043,38 @@ __global__ void k_copy_columns(MsaView mv, u64 col0, u64 ncols, uint8_t* __restr
     }
 }
 
-// first / last segment of the planned alignment: type, width and text sizes (for the slab stitch)
+// first / last segment of the planned alignment: type, width and text sizes (for the slab stitch).  One small kernel
+// gathers the ten numbers, one copy brings them over (the stitch runs inside every multi-GPU step).
+__global__ void k_edge_info(const u64* __restrict__ seg_start, const u64* __restrict__ eds_off, const u64* __restrict__ seds_off,
+                            const u64* __restrict__ V, u64 nseg, u64 L, u64* __restrict__ out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    out[0] = seg_start[0]; out[1] = nseg > 1 ? seg_start[1] : L; out[2] = seg_start[nseg - 1];
+    out[3] = nseg > 1 ? eds_off[1] : 0; out[4] = nseg > 1 ? seds_off[1] : 0;
+    out[5] = eds_off[nseg - 1]; out[6] = seds_off[nseg - 1];
+    out[7] = V[0] & 1ull; out[8] = (V[(L - 1) >> 6] >> ((L - 1) & 63)) & 1ull;
+}
+
 MsaPipeline::Edges MsaPipeline::edge_info(hipStream_t st)
 {
     if (!planned_) throw ParamError("edge_info needs a planned alignment");
     const u64 nseg = h_.nseg;
     Edges e{};
     e.nseg = nseg;
-    u64 ss[2], sl[1], eo[2], so[2], el[1], slo[1], v0 = 0, vl = 0;
-    EDSX_HIP(hipMemcpyAsync(ss, seg_start_p_, 16, hipMemcpyDeviceToHost, st));
-    EDSX_HIP(hipMemcpyAsync(sl, seg_start_p_ + (nseg - 1), 8, hipMemcpyDeviceToHost, st));
-    EDSX_HIP(hipMemcpyAsync(eo, eds_len_.as<u64>(), nseg > 1 ? 16 : 8, hipMemcpyDeviceToHost, st));
-    EDSX_HIP(hipMemcpyAsync(so, seds_len_.as<u64>(), nseg > 1 ? 16 : 8, hipMemcpyDeviceToHost, st));
-    EDSX_HIP(hipMemcpyAsync(el, eds_len_.as<u64>() + (nseg - 1), 8, hipMemcpyDeviceToHost, st));
-    EDSX_HIP(hipMemcpyAsync(slo, seds_len_.as<u64>() + (nseg - 1), 8, hipMemcpyDeviceToHost, st));
-    EDSX_HIP(hipMemcpyAsync(&v0, mv_.V, 8, hipMemcpyDeviceToHost, st));
-    EDSX_HIP(hipMemcpyAsync(&vl, mv_.V + ((h_.L - 1) >> 6), 8, hipMemcpyDeviceToHost, st));
+    idx_tmp_.ensure(16 * sizeof(u64));
+    u64 h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_edge_info, dim3(1), dim3(64), 0, st, seg_start_p_, eds_len_.as<u64>(), seds_len_.as<u64>(), mv_.V, nseg, h_.L,
+                       idx_tmp_.as<u64>());
+    EDSX_HIP(hipMemcpyAsync(h, idx_tmp_.ptr, sizeof(h), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
-    e.fvar = v0 & 1;
-    e.fcols = (nseg > 1 ? ss[1] : h_.L) - ss[0];
-    e.feds = nseg > 1 ? eo[1] : h_.E;
-    e.fseds = nseg > 1 ? so[1] : h_.Q;
-    e.lvar = (vl >> ((h_.L - 1) & 63)) & 1;
-    e.lcols = h_.L - sl[0];
-    e.leds = h_.E - el[0];
-    e.lseds = h_.Q - slo[0];
+    e.fvar = h[7];
+    e.fcols = h[1] - h[0];
+    e.feds = nseg > 1 ? h[3] : h_.E;
+    e.fseds = nseg > 1 ? h[4] : h_.Q;
+    e.lvar = h[8];
+    e.lcols = h_.L - h[2];
+    e.leds = h_.E - h[5];
+    e.lseds = h_.Q - h[6];
     return e;
 }
 
