@@ -1604,6 +1604,7 @@ constexpr u64 META_KIND8 = 1ull << 60;    // 8-bit group ids (17..64 strings)
 constexpr u64 META_RECID = (1ull << 40) - 1;
 constexpr u64 CNT_SCATTER = 1ull << 63;   // count-list descriptor: ncol << 48 | slot of the first column
 constexpr u64 CNT_SLOT = (1ull << 48) - 1;
+constexpr u64 CNT_MIXED = 1ull << 62;     // a segment of an l-EDS with common columns between its variant runs (heavy grouping kernel)
 // record header (behind the group ids): +0 u32 k | textlen << 8 | ncol << 16;  +8 u64 slot0 | CNT_SCATTER;
 // +16 u16 rep[16] (first row of every string);  +48 text[80]
 constexpr u32 REC_H_SLOT = 8, REC_H_REP = 16;
@@ -1653,6 +1654,7 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
                 if (pure) contig = contig && mv.slot(c) == s0 + (c - a);
             }
             if (pure) cm = (ncol << 48) | s0 | (contig ? 0 : CNT_SCATTER);
+            else cm = (ncol << 48) | s0 | CNT_MIXED;      // context merge: common columns inside (every row has the reference byte there)
         }
         if (!cm) p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;        // too wide or mixed columns
         p.segmeta[seg] = 0;                               // k_seg_group fills it in
@@ -1727,8 +1729,10 @@ template <int MAXG> __device__ __forceinline__ uint32_t lutN(const u32* t, uint3
 // ends a row's string at NUL, msa_transforms.cpp:282) are built once from the first rows, and raw groups that
 // spell one string are joined.  More than 64 raw groups, or a NUL inside the segment: generic kernels.
 // Returns 1 grouped, 0 generic kernels (NUL), -1 more than MAXG raw groups.
-template <int MAXG, bool CHECK_NL, class ColPtr, class CellPtr>
-__device__ __forceinline__ int refine_groups(ColPtr col_ptr, CellPtr cell_ptr, u32 ncol, const uint4& col0, u32 lane, const uint4& vmask,
+// load_col(c): this lane's 16 bytes of column c; cell(c, row): one byte (a common column inside an l-EDS segment is the
+// reference byte in every row: it splits no group, but its letter belongs to every string).
+template <int MAXG, bool CHECK_NL, class LoadCol, class Cell>
+__device__ __forceinline__ int refine_groups(LoadCol load_col, Cell cell, u32 ncol, const uint4& col0, u32 lane, const uint4& vmask,
                                              FastGroups& G, u32& saw_nl, uint8_t* strs)
 {
     uint4 gid = make_uint4(~vmask.x, ~vmask.y, ~vmask.z, ~vmask.w);        // group 0; rows that do not exist: 0xFF
@@ -1738,7 +1742,7 @@ __device__ __forceinline__ int refine_groups(ColPtr col_ptr, CellPtr cell_ptr, u
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             cvs[j] = make_uint4(0, 0, 0, 0);
-            if (c0 + j < ncol) cvs[j] = (c0 + j == 0) ? col0 : load16u(col_ptr(c0 + j));
+            if (c0 + j < ncol) cvs[j] = (c0 + j == 0) ? col0 : load_col(c0 + j);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1795,7 +1799,7 @@ __device__ __forceinline__ int refine_groups(ColPtr col_ptr, CellPtr cell_ptr, u
                 const u32 gs = (u32)__builtin_ctzll(ballot64(lane < k && rank_l == r0 + i));
                 const u32 row = (u32)__builtin_amdgcn_readlane((int)rep_l, (int)gs);
                 if (lane < ncol) {
-                    chv[i] = cell_ptr(lane)[row];
+                    chv[i] = cell(lane, row);
                 }
             }
         }
@@ -1879,7 +1883,8 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
     }
 
     const u64 slot0 = cmeta & CNT_SLOT;
-    const bool scatter = (cmeta & CNT_SCATTER) != 0;
+    const bool scatter = (cmeta & CNT_SCATTER) != 0, mixed = (cmeta & CNT_MIXED) != 0;
+    if (mixed && !HEAVY) return 2;
     const u32 loff = lane * 16u < mv.Spad - 16u ? lane * 16u : mv.Spad - 16u;     // lanes without rows stay inside the column
     const uint8_t* cbase = mv.vc + slot0 * (u64)mv.Spad + loff;
     // A segment whose slots are not consecutive crosses a tile edge of the column scan (once: it has at most 64
@@ -1898,7 +1903,7 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
     };
 
     if (!HEAVY && ncol > 10u) return 2;
-    if (ncol <= 10u) {
+    if (ncol <= 10u && !mixed) {
         auto load_col = [&](u32 c) -> uint4 { return load16u(col_ptr(c)); };
         const int r = fast_group_dnakeys<1>(load_col, ncol, col0, lane, vmask, G);
         if (r) return r > 0 ? 1 : 0;
@@ -1906,7 +1911,7 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
         G.k = 0; G.sumlen = 0; G.key_lo = 0; G.key_hi = 0; G.rep = 0; G.len = 0;
     }
     if constexpr (HEAVY) {
-        if (ncol > 10u && ncol <= 20u) {                   // 11..20 columns over the DNA alphabet: exact keys in two dwords
+        if (ncol > 10u && ncol <= 20u && !mixed) {         // 11..20 columns over the DNA alphabet: exact keys in two dwords
             auto load_col = [&](u32 c) -> uint4 { return load16u(col_ptr(c)); };
             const int r = fast_group_dnakeys<2>(load_col, ncol, col0, lane, vmask, G);
             if (r) return r > 0 ? 1 : 0;
@@ -1918,8 +1923,19 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
                                     : (scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + loff : cbase + (u64)c * mv.Spad);
             return cp - loff;
         };
-        int r = refine_groups<16, CHECK_NL>(col_ptr, cell_ptr, ncol, col0, lane, vmask, G, saw_nl, strs);
-        if (r < 0) r = refine_groups<64, CHECK_NL>(col_ptr, cell_ptr, ncol, col0, lane, vmask, G, saw_nl, strs);   // (rare: 17..64 raw groups)
+        auto load_colx = [&](u32 c) -> uint4 {
+            if (mixed) {
+                if (!mv.vbit(seg_a + c)) { const u32 b = mv.ref_byte(seg_a + c) * 0x01010101u; return make_uint4(b, b, b, b); }
+                return load16u(mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + loff);
+            }
+            return load16u(col_ptr(c));
+        };
+        auto cell = [&](u32 c, u32 row) -> u32 {
+            if (mixed) return mv.vbit(seg_a + c) ? (u32)mv.vc[mv.slot(seg_a + c) * (u64)mv.Spad + row] : mv.ref_byte(seg_a + c);
+            return (u32)cell_ptr(c)[row];
+        };
+        int r = refine_groups<16, CHECK_NL>(load_colx, cell, ncol, col0, lane, vmask, G, saw_nl, strs);
+        if (r < 0) r = refine_groups<64, CHECK_NL>(load_colx, cell, ncol, col0, lane, vmask, G, saw_nl, strs);   // (rare: 17..64 raw groups)
         return r > 0 ? 1 : 0;
     } else return 2;
 }
@@ -1964,7 +1980,7 @@ __global__ void __launch_bounds__(256, HEAVY ? 2 : 4) k_seg_group(FastParams p)
         const u64 cm_v = lcm[i2], vi_v = lvi[i2];             // scalar after the wait below
         const u32 ncol = (u32)(cmeta >> 48) & 0xffu;
         FastGroups G;
-        const int ok = fast_group<true, HEAVY>(mv, (cmeta & CNT_SCATTER) ? uniform64(p.seg_start[seg]) : 0, cmeta, col, rb, lane, vmask, G, saw_nl, strs);
+        const int ok = fast_group<true, HEAVY>(mv, (cmeta & (CNT_SCATTER | CNT_MIXED)) ? uniform64(p.seg_start[seg]) : 0, cmeta, col, rb, lane, vmask, G, saw_nl, strs);
         // wait for the prefetched column here, before this segment's stores are queued behind it
         // (vmcnt retires in issue order)
         asm volatile("" :: "v"(col_n.x), "v"(col_n.y), "v"(col_n.z), "v"(col_n.w), "v"(rb_n), "v"(cm_v), "v"(vi_v));
@@ -1979,7 +1995,7 @@ __global__ void __launch_bounds__(256, HEAVY ? 2 : 4) k_seg_group(FastParams p)
             if (lane < G.k) *reinterpret_cast<uint16_t*>(hdr + REC_H_REP + lane * 2u) = (uint16_t)G.rep;
             if (lane == 0) {
                 *reinterpret_cast<u32*>(hdr) = G.k | (ncol << 16);
-                *reinterpret_cast<u64*>(hdr + REC_H_SLOT) = cmeta & (CNT_SLOT | CNT_SCATTER);
+                *reinterpret_cast<u64*>(hdr + REC_H_SLOT) = cmeta & (CNT_SLOT | CNT_SCATTER | CNT_MIXED);
                 p.eds_len[seg] = 2 + (u64)(G.k - 1) + G.sumlen;
                 p.seds_len[seg] = (u64)G.k + p.tok_total;
                 p.segmeta[seg] = META_REC | (G.k > 16u ? META_KIND8 : G.k > 4u ? META_KIND4 : 0) | vi;
@@ -2443,16 +2459,20 @@ __global__ void __launch_bounds__(256, 5) k_emit_fast2(FastParams p)
                 const u32 ncol = (hdr0 >> 16) & 0xffu;
                 const u64 cm = uniform64(rc.cm);
                 const u64 slot0 = cm & CNT_SLOT;
-                const bool scatter = (cm & CNT_SCATTER) != 0;
-                const u64 seg_a = scatter ? uniform64(p.seg_start[seg]) : 0;
+                const bool scatter = (cm & CNT_SCATTER) != 0, mixed = (cm & CNT_MIXED) != 0;
+                const u64 seg_a = (scatter || mixed) ? uniform64(p.seg_start[seg]) : 0;
+                auto cell = [&](u32 c, u32 r) -> u32 {         // byte of row r in column c of the segment
+                    if (mixed && !mv.vbit(seg_a + c)) return mv.ref_byte(seg_a + c);
+                    const u64 sl = (scatter || mixed) ? mv.slot(seg_a + c) : slot0 + c;
+                    return mv.vc[sl * (u64)mv.Spad + r];
+                };
                 const u32 rep_l = lane < k ? rc.rep : 0u;
                 if (k * ncol <= 64u) {                         // lane = (string, column): one load round trip
                     const u32 g = lane / ncol, c = lane - g * ncol;
                     const u32 r = (u32)__shfl((int)rep_l, (int)(g < k ? g : 0u), 64);
                     u32 ch = 0;
                     if (g < k) {
-                        const u64 sl = scatter ? mv.slot(seg_a + c) : slot0 + c;
-                        ch = mv.vc[sl * (u64)mv.Spad + r];
+                        ch = cell(c, r);
                         if (ch == '-' || ch == '\n') ch = 0;
                     }
                     const u64 m = ballot64(ch != 0);
@@ -2470,8 +2490,7 @@ __global__ void __launch_bounds__(256, 5) k_emit_fast2(FastParams p)
                         const u32 r = (u32)__builtin_amdgcn_readlane((int)rep_l, (int)g);
                         u32 ch = 0;
                         if (lane < ncol) {
-                            const u64 sl = scatter ? mv.slot(seg_a + lane) : slot0 + lane;
-                            ch = mv.vc[sl * (u64)mv.Spad + r];
+                            ch = cell(lane, r);
                             if (ch == '-' || ch == '\n') ch = 0;
                         }
                         const u64 m = ballot64(ch != 0);
@@ -2588,16 +2607,20 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
             } else {
                 const u64 cm = uniform64(rc.cm);
                 const u64 slot0 = cm & CNT_SLOT;
-                const bool scatter = (cm & CNT_SCATTER) != 0;
-                const u64 seg_a = scatter ? uniform64(p.seg_start[seg]) : 0;
+                const bool scatter = (cm & CNT_SCATTER) != 0, mixed = (cm & CNT_MIXED) != 0;
+                const u64 seg_a = (scatter || mixed) ? uniform64(p.seg_start[seg]) : 0;
+                auto cell = [&](u32 c, u32 r) -> u32 {         // byte of row r in column c of the segment
+                    if (mixed && !mv.vbit(seg_a + c)) return mv.ref_byte(seg_a + c);
+                    const u64 sl = (scatter || mixed) ? mv.slot(seg_a + c) : slot0 + c;
+                    return mv.vc[sl * (u64)mv.Spad + r];
+                };
                 const u32 rep_l = lane < k ? rc.rep : 0u;
                 if (k * ncol <= 64u) {                         // lane = (string, column): one load round trip
                     const u32 g = lane / ncol, c = lane - g * ncol;
                     const u32 r = (u32)__shfl((int)rep_l, (int)(g < k ? g : 0u), 64);
                     u32 ch = 0;
                     if (g < k) {
-                        const u64 sl = scatter ? mv.slot(seg_a + c) : slot0 + c;
-                        ch = mv.vc[sl * (u64)mv.Spad + r];
+                        ch = cell(c, r);
                         if (ch == '-' || ch == '\n') ch = 0;
                     }
                     const u64 m = ballot64(ch != 0);
@@ -2615,8 +2638,7 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
                         const u32 r = (u32)__builtin_amdgcn_readlane((int)rep_l, (int)g);
                         u32 ch = 0;
                         if (lane < ncol) {
-                            const u64 sl = scatter ? mv.slot(seg_a + lane) : slot0 + lane;
-                            ch = mv.vc[sl * (u64)mv.Spad + r];
+                            ch = cell(lane, r);
                             if (ch == '-' || ch == '\n') ch = 0;
                         }
                         const u64 m = ballot64(ch != 0);
