@@ -1747,6 +1747,7 @@ __device__ __forceinline__ int refine_groups(LoadCol load_col, Cell cell, u32 nc
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (c0 + j >= ncol) continue;
+            if (cell(c0 + j, ~0u) < 0x100u) continue;           // a common column splits no group (row ~0: "is it common?")
             const uint4 col = cvs[j];
             u32 t[MAXG / 4];                                  // byte g & 7 of (t[2q+1]:t[2q]), q = g >> 3: this column's byte of group g's first row
 #pragma unroll
@@ -1923,15 +1924,25 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
                                     : (scatter ? mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + loff : cbase + (u64)c * mv.Spad);
             return cp - loff;
         };
-        auto load_colx = [&](u32 c) -> uint4 {
+        // mixed segment: lane c looks its column up once (variant: slot in vc; common: the reference byte) - one round of
+        // dependent loads for all columns together instead of one per column inside the refinement loop
+        u32 cs_lo = 0, cs_hi = 0, cref = 0x100u;               // cref < 0x100: a common column
+        if (mixed && lane < ncol) {
+            if (mv.vbit(seg_a + lane)) { const u64 sl = mv.slot(seg_a + lane); cs_lo = (u32)sl; cs_hi = (u32)(sl >> 32); }
+            else cref = mv.ref_byte(seg_a + lane);
+        }
+        auto load_colx = [&](u32 c) -> uint4 {                 // c is wave-uniform
             if (mixed) {
-                if (!mv.vbit(seg_a + c)) { const u32 b = mv.ref_byte(seg_a + c) * 0x01010101u; return make_uint4(b, b, b, b); }
-                return load16u(mv.vc + mv.slot(seg_a + c) * (u64)mv.Spad + loff);
+                const u32 rb = (u32)__builtin_amdgcn_readlane((int)cref, (int)c);
+                if (rb < 0x100u) { const u32 b = rb * 0x01010101u; return make_uint4(b, b, b, b); }
+                const u64 sl = ((u64)(u32)__builtin_amdgcn_readlane((int)cs_hi, (int)c) << 32) | (u32)__builtin_amdgcn_readlane((int)cs_lo, (int)c);
+                return load16u(mv.vc + sl * (u64)mv.Spad + loff);
             }
             return load16u(col_ptr(c));
         };
-        auto cell = [&](u32 c, u32 row) -> u32 {
-            if (mixed) return mv.vbit(seg_a + c) ? (u32)mv.vc[mv.slot(seg_a + c) * (u64)mv.Spad + row] : mv.ref_byte(seg_a + c);
+        auto cell = [&](u32 c, u32 row) -> u32 {               // row == ~0: (uniform c) the reference byte of a common column, else 0x100
+            if (row == ~0u) return mixed ? (u32)__builtin_amdgcn_readlane((int)cref, (int)c) : 0x100u;
+            if (mixed) return cref < 0x100u ? cref : (u32)mv.vc[(((u64)cs_hi << 32) | cs_lo) * (u64)mv.Spad + row];   // c == lane
             return (u32)cell_ptr(c)[row];
         };
         int r = refine_groups<16, CHECK_NL>(load_colx, cell, ncol, col0, lane, vmask, G, saw_nl, strs);
