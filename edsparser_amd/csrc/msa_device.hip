@@ -1211,20 +1211,22 @@ __device__ const uint8_t* stage_columns(const MsaView& mv, u64 a, u64 b, uint8_t
     if (!buf || ncol > cap_cols) return nullptr;
     u64* slot_tab = reinterpret_cast<u64*>(buf);              // cap_cols entries, then the columns
     uint8_t* cols = buf + (size_t)cap_cols * 8;
-    if (threadIdx.x == 0) *flag_sh = 0;
-    __syncthreads();
+    (void)flag_sh;
+    __syncthreads();                                          // (the previous segment is done with the staging area)
     if (threadIdx.x < ncol) {
         const u64 c = a + threadIdx.x;
-        if (mv.vbit(c)) slot_tab[threadIdx.x] = mv.slot(c);
-        else *flag_sh = 1;                                    // a common column inside (context merge): not staged
+        // a common column inside (context merge): every row has the reference byte there
+        slot_tab[threadIdx.x] = mv.vbit(c) ? mv.slot(c) : ((1ull << 63) | mv.ref_byte(c));
     }
     __syncthreads();
-    if (*flag_sh) return nullptr;
     const u32 vec = mv.Spad / 16;                             // Spad % 16 == 0
     for (u32 i = threadIdx.x; i < (u32)ncol * vec; i += blockDim.x) {
         const u32 c = i / vec, o = (i - c * vec) * 16;
-        *reinterpret_cast<uint4*>(cols + (size_t)c * mv.Spad + o) =
-            *reinterpret_cast<const uint4*>(mv.vc + slot_tab[c] * (u64)mv.Spad + o);
+        const u64 sl = slot_tab[c];
+        uint4 v;
+        if (sl >> 63) { const u32 b4 = (u32)(sl & 0xffu) * 0x01010101u; v = make_uint4(b4, b4, b4, b4); }
+        else v = *reinterpret_cast<const uint4*>(mv.vc + sl * (u64)mv.Spad + o);
+        *reinterpret_cast<uint4*>(cols + (size_t)c * mv.Spad + o) = v;
     }
     __syncthreads();
     return cols;
