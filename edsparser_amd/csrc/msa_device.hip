@@ -1540,8 +1540,82 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
         }
         __syncthreads();
 
-        // ---- seds: wave 0 walks the rows in order; run[g] = next write offset of group g
-        if (threadIdx.x < 64) {
+        // ---- seds: run[g] = next write offset of group g.  A row's token goes behind the tokens of the earlier rows of its
+        // group.  When the staging area (free again: the .eds text is written) holds the tables, all four waves work on
+        // it: (A) every wave takes every fourth 64-row block and finds, per distinct group of the block, the bytes of its
+        // rows and every row's offset among them; (B) wave 0 walks the blocks in order and turns the per-block group
+        // totals into start offsets (a block's groups are distinct: one lane each); (C) all waves store their tokens.
+        // Otherwise (no staging area: very many rows) wave 0 walks the rows block by block.
+        const u32 nblk = (S + 63u) >> 6, S2 = (S + 1u) & ~1u, wv = uniform32(threadIdx.x >> 6);
+        const size_t walk_bytes = (size_t)nblk * 384 + (size_t)S2 * 2 + S2 + nblk + 16;
+        const bool par = p.stage_cols != 0 && walk_bytes <= (size_t)p.stage_cols * (8 + (size_t)mv.Spad);
+        auto token_of = [&](u32 r, u32 tl) -> u64 {            // "ddd," little-endian: first digit in byte 0
+            u64 tok = (u64)',' << (8 * (tl - 1));
+            u32 v = r + 1;
+            for (int i = (int)tl - 2; i >= 0; i--) { tok |= (u64)('0' + v % 10u) << (8 * i); v /= 10u; }
+            return tok;
+        };
+        auto store_token = [&](uint8_t* dst, u64 tok, u32 tl) {
+            dst[0] = (uint8_t)tok; dst[1] = (uint8_t)(tok >> 8);
+            if (tl >= 3) dst[2] = (uint8_t)(tok >> 16);
+            if (tl >= 4) dst[3] = (uint8_t)(tok >> 24);
+            if (tl >= 5) dst[4] = (uint8_t)(tok >> 32);
+            if (tl >= 6) for (u32 i = 5; i < tl; i++) dst[i] = (uint8_t)(tok >> (8 * i));
+        };
+        if (par) {
+            uint8_t* wb = lds_raw + p.stage_off;
+            u32* LT = reinterpret_cast<u32*>(wb);                                  // [block][i]: bytes of the block's i-th group, then its start
+            uint16_t* LG = reinterpret_cast<uint16_t*>(wb + (size_t)nblk * 256);   // [block][i]: that group
+            uint16_t* REL = reinterpret_cast<uint16_t*>(wb + (size_t)nblk * 384);  // [row]: bytes of the earlier rows of its group in its block
+            uint8_t* IDX = wb + (size_t)nblk * 384 + (size_t)S2 * 2;               // [row]: index of its group in its block's list
+            uint8_t* NG = IDX + S2;                                                // [block]: distinct groups
+            for (u32 blk = wv; blk < nblk; blk += GT / 64) {                       // (A)
+                const u32 r = blk * 64u + lane;
+                const bool valid = r < S;
+                const u32 g = valid ? lds.gid[r] : 0xffffffffu;
+                const u32 tl = ndigits(r + 1) + 1;
+                const u32 tlA = __shfl(tl, 0, 64);              // <= 2 token lengths per 64 rows
+                const u64 maskA = ballot64(valid && tl == tlA);
+                u32 myrel = 0, myidx = 0, idx = 0;
+                u64 todo = ballot64(valid);
+                while (todo) {
+                    const int leader = __builtin_ctzll(todo);
+                    const u32 g0 = (u32)__builtin_amdgcn_readlane((int)g, leader);
+                    const u64 m = ballot64(valid && g == g0);
+                    if (valid && g == g0) { myrel = mbcnt(m & maskA) * tlA + mbcnt(m & ~maskA) * (tlA + 1); myidx = idx; }
+                    if (lane == (u32)leader) {
+                        LG[blk * 64u + idx] = (uint16_t)g0;
+                        LT[blk * 64u + idx] = (u32)__builtin_popcountll(m & maskA) * tlA + (u32)__builtin_popcountll(m & ~maskA) * (tlA + 1);
+                    }
+                    idx++;
+                    todo &= ~m;
+                }
+                if (valid) { REL[r] = (uint16_t)myrel; IDX[r] = (uint8_t)myidx; }
+                if (lane == 0) NG[blk] = (uint8_t)idx;            // <= 64
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {                                                // (B)
+                for (u32 blk = 0; blk < nblk; blk++) {
+                    if (lane < (u32)NG[blk]) {
+                        const u32 g0 = LG[blk * 64u + lane], start = lds.run[g0];
+                        lds.run[g0] = start + LT[blk * 64u + lane];
+                        LT[blk * 64u + lane] = start;
+                    }
+                }
+            }
+            __syncthreads();
+            for (u32 blk = wv; blk < nblk; blk += GT / 64) {                       // (C)
+                const u32 r = blk * 64u + lane;
+                if (r < S) {
+                    const u32 tl = ndigits(r + 1) + 1;
+                    store_token(seds + LT[blk * 64u + IDX[r]] + REL[r], token_of(r, tl), tl);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0);                     // every wave's stores have landed before the braces overwrite the last ','
+            __syncthreads();
+            if (threadIdx.x < 64)
+                for (u32 g = lane; g < k; g += 64) seds[lds.run[g] - 1] = '}';
+        } else if (threadIdx.x < 64) {
             for (u32 base = 0; base < S; base += 64) {
                 const u32 r = base + lane;
                 const bool valid = r < S;
@@ -1549,8 +1623,6 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
                 const u32 tl = ndigits(r + 1) + 1;
                 const u32 tlA = __shfl(tl, 0, 64);              // <= 2 token lengths per 64 rows
                 const u64 maskA = ballot64(valid && tl == tlA);
-                u64 tok = (u64)',' << (8 * (tl - 1));           // "ddd," little-endian: first digit in byte 0
-                { u32 v = r + 1; for (int i = (int)tl - 2; i >= 0; i--) { tok |= (u64)('0' + v % 10u) << (8 * i); v /= 10u; } }
                 // placement: one wave-uniform step per distinct group of the block; the stores follow the
                 // loop, all lanes together (inside it they would run once per group, a few lanes at a time)
                 u32 myoff = 0;
@@ -1566,14 +1638,7 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
                     if (lane == (u32)leader) lds.run[g0] = start + tot;
                     todo &= ~m;
                 }
-                if (valid) {
-                    uint8_t* dst = seds + myoff;
-                    dst[0] = (uint8_t)tok; dst[1] = (uint8_t)(tok >> 8);
-                    if (tl >= 3) dst[2] = (uint8_t)(tok >> 16);
-                    if (tl >= 4) dst[3] = (uint8_t)(tok >> 24);
-                    if (tl >= 5) dst[4] = (uint8_t)(tok >> 32);
-                    if (tl >= 6) for (u32 i = 5; i < tl; i++) dst[i] = (uint8_t)(tok >> (8 * i));
-                }
+                if (valid) store_token(seds + myoff, token_of(r, tl), tl);
             }
             // every store above must have landed before the closing braces overwrite the last ','
             __builtin_amdgcn_s_waitcnt(0);
