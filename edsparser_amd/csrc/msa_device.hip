@@ -1409,7 +1409,11 @@ struct SegParams {
     MsaView mv; const u64* seg_start; const u64* nseg_ptr; u64* eds_len; u64* seds_len; u64 tok_total;
     const u64* list; const u64* list_n;       // when set: only these segments (left over by the fast path)
     u32 stage_cols = 0, stage_off = 0;        // LDS column staging: capacity in columns, byte offset in the dynamic LDS
+    // grouping cache (count -> emit): item `it` of the list (or segment `it`) keeps k, its group ids and first rows
+    uint8_t* gcache = nullptr; u64 gcache_cap = 0; u32 gcache_stride = 0;
 };
+// cache entry: u32 k, pad; u16 gid[S (rounded up to 8)]; u32 rep_row[S]
+__host__ __device__ inline u32 gcache_stride_of(u32 S) { return 16u + ((S + 7u) & ~7u) * 2u + S * 4u; }
 
 // K3: per-segment output sizes.  common: "{" ref "}" and "{0}"; variant: see generate_output.
 __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
@@ -1430,6 +1434,14 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
         if (threadIdx.x == 0) sum_sh = 0;
         const uint8_t* st = stage_columns(p.mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, p.stage_cols, &rep_sh);
         const u32 k = group_segment(p.mv, a, b, lds, &rep_sh, st);
+        if (it < p.gcache_cap) {                             // the emitter takes the grouping from here
+            uint8_t* ce = p.gcache + it * (u64)p.gcache_stride;
+            uint16_t* cg = reinterpret_cast<uint16_t*>(ce + 16);
+            u32* cr = reinterpret_cast<u32*>(ce + 16 + ((p.mv.S + 7u) & ~7u) * 2u);
+            if (threadIdx.x == 0) *reinterpret_cast<u32*>(ce) = k;
+            for (u32 r = threadIdx.x; r < p.mv.S; r += GT) cg[r] = lds.gid[r];
+            for (u32 g = threadIdx.x; g < k; g += GT) cr[g] = lds.rep_row[g];
+        }
         const SegCells sc{p.mv, a, st};
         u64 mine = 0;
         for (u32 g = threadIdx.x; g < k; g += GT) mine += seg_row_len(sc, a, b, lds.rep_row[g]);
@@ -1452,6 +1464,7 @@ struct EmitParams {
     const u64* eds_off; const u64* seds_off; uint8_t* eds; uint8_t* seds; u64 nwords;
     const u64* list; const u64* list_n;
     u32 stage_cols = 0, stage_off = 0;
+    const uint8_t* gcache = nullptr; u64 gcache_cap = 0; u32 gcache_stride = 0;      // see SegParams
 };
 
 __global__ void __launch_bounds__(256) k_emit_common(EmitParams p)
@@ -1502,7 +1515,17 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         if (!mv.vbit(a)) continue;
         const uint8_t* st = stage_columns(mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, p.stage_cols, &rep_sh);
-        const u32 k = group_segment(mv, a, b, lds, &rep_sh, st);
+        u32 k;
+        if (it < p.gcache_cap) {                             // grouped by k_seg_count already
+            const uint8_t* ce = p.gcache + it * (u64)p.gcache_stride;
+            const uint16_t* cg = reinterpret_cast<const uint16_t*>(ce + 16);
+            const u32* cr = reinterpret_cast<const u32*>(ce + 16 + ((S + 7u) & ~7u) * 2u);
+            k = *reinterpret_cast<const u32*>(ce);
+            __syncthreads();                                  // (the previous segment's readers of gid / rep_row are done)
+            for (u32 r = threadIdx.x; r < S; r += GT) lds.gid[r] = cg[r];
+            for (u32 g = threadIdx.x; g < k; g += GT) lds.rep_row[g] = cr[g];
+            __syncthreads();
+        } else k = group_segment(mv, a, b, lds, &rep_sh, st);
         const SegCells sc{mv, a, st};
         uint8_t* eds = p.eds + p.eds_off[seg];
         uint8_t* seds = p.seds + p.seds_off[seg];
@@ -3058,6 +3081,12 @@ void MsaPipeline::plan_body(hipStream_t st)
         }
     }
 
+    // grouping cache of the generic kernels (count -> emit): two regions (one per work list; without lists: both)
+    gc_stride_ = gcache_stride_of((u32)S);
+    gc_region_ = (size_t)std::min<u64>((u64)1 << 30, (L / 2 + 4) * (u64)gc_stride_);
+    gc_region_ = gc_region_ / gc_stride_ * gc_stride_;
+    gcache_.ensure(2 * gc_region_ + 16);
+
     const u64 tok_total = token_total((u32)S);
     fast_ = S <= 1024;
     SegParams sp;
@@ -3099,11 +3128,13 @@ void MsaPipeline::plan_body(hipStream_t st)
         TIMED("k_heavy_scatter", st, hipLaunchKernelGGL(k_heavy_scatter, dim3(2048), dim3(256), 0, st, fp_, fp_.cnt_flag));
         TIMED("k_seg_group_heavy", st, hipLaunchKernelGGL(k_seg_group<true>, dim3(persistent_grid(
                   reinterpret_cast<const void*>(k_seg_group<true>), 256, 0)), dim3(256), 0, st, fp_));
-        sp.list = fp_.slow_list; sp.list_n = fp_.slow_count;
+        sp.gcache_stride = gc_stride_; sp.gcache_cap = gc_region_ / gc_stride_;
+        sp.list = fp_.slow_list; sp.list_n = fp_.slow_count; sp.gcache = gcache_.as<uint8_t>();
         TIMED("k_seg_count_slow", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
-        sp.list = fp_.slow_list2; sp.list_n = fp_.slow_count2;
+        sp.list = fp_.slow_list2; sp.list_n = fp_.slow_count2; sp.gcache = gcache_.as<uint8_t>() + gc_region_;
         TIMED("k_seg_count_slow2", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
     } else {
+        sp.gcache_stride = gc_stride_; sp.gcache_cap = 2 * gc_region_ / gc_stride_; sp.gcache = gcache_.as<uint8_t>();
         TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
     }
     TIMED("scan_eds", st, exclusive_scan_u64(eds_len_.as<u64>(), eds_len_.as<u64>(), d_nseg, &dh->E,
@@ -3257,9 +3288,10 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
             if (h_.S >= 1000) launch_wide(k_emit_fast<true, true>);      // ids of five bytes exist
             else launch_wide(k_emit_fast<false, true>);
         }
-        ep.list = fp_.slow_list; ep.list_n = fp_.slow_count;
+        ep.gcache_stride = gc_stride_; ep.gcache_cap = gc_region_ / gc_stride_;
+        ep.list = fp_.slow_list; ep.list_n = fp_.slow_count; ep.gcache = gcache_.as<uint8_t>();
         TIMED("k_emit_variant_slow", s2, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
-        ep.list = fp_.slow_list2; ep.list_n = fp_.slow_count2;
+        ep.list = fp_.slow_list2; ep.list_n = fp_.slow_count2; ep.gcache = gcache_.as<uint8_t>() + gc_region_;
         TIMED("k_emit_variant_slow2", s2, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
         if (side_env) {
             EDSX_HIP(hipEventRecord(side_ev_[1], s1));
@@ -3269,6 +3301,7 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
         }
     } else {
         TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
+        ep.gcache_stride = gc_stride_; ep.gcache_cap = 2 * gc_region_ / gc_stride_; ep.gcache = gcache_.as<uint8_t>();
         TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
     }
     EDSX_HIP(hipGetLastError());

@@ -175,7 +175,7 @@ private:
     std::vector<TimedKernel> timed_;
 
     DevBuf hdr_, rows_, vraw_, v_, wslot_, vc_, hrun_, hseg_, cnt_, wbase_, segbase_, scan_tmp_,
-           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, cnt_list_, rec_, recf_, rec_info_, fraw_, colbuf_, idx_tmp_;
+           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, cnt_list_, rec_, recf_, rec_info_, fraw_, colbuf_, idx_tmp_, gcache_;
     u64 vc_cap_cols_ = 0;
 
     // emit-time view
@@ -186,6 +186,8 @@ private:
     u32 stage_off_ = 0, stage_cols_ = 0;   // generic kernels: column staging area in their LDS (offset, capacity; 0: none)
     bool fast_ = false, fuse_ = false;
     u32 recf_stride_ = 0, recf_gid_ = 0;
+    u32 gc_stride_ = 0;                      // grouping cache of the generic kernels: entry size, bytes per region
+    size_t gc_region_ = 0;
     FastParams fp_{};
     int cus_ = 0;
     // side streams of emit(): the small emitters run next to each other
