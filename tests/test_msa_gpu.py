@@ -81,7 +81,13 @@ def test_trailing_blank_lines_tolerated(ctx):
 
 
 @pytest.mark.parametrize("S,L,l", [(48, 20000, 0), (48, 20000, 10), (64, 200000, 0), (1000, 30000, 0),
-                                    (1000, 30000, 6), (7, 100003, 0)])
+                                    (1000, 30000, 6), (7, 100003, 0),
+                                    # l-EDS at the bench's row count: mixed segments through the heavy grouping kernel
+                                    # (<= 64 columns), > 64 strings / > 64 columns through the generic kernels (staged
+                                    # mixed segments, four-wave .seds walk, grouping cache)
+                                    (1000, 60000, 3), (1000, 60000, 10), (1000, 40000, 32), (300, 50000, 10), (64, 100000, 10),
+                                    # more than 1024 rows: the generic kernels take every variant segment
+                                    (2000, 20000, 0), (2000, 20000, 5), (3000, 6000, 0)])
 def test_synthetic_device_path(ctx, S, L, l):
     """genrandomeds-shaped alignment generated in HBM, device-resident plan/emit vs the oracle."""
     import torch
