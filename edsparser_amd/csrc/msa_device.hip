@@ -1195,41 +1195,77 @@ struct SegLds {
 // Cells of one segment.  Read from HBM a cell costs a chain of dependent loads (V word, slot table,
 // vc byte); segments of up to STAGE_COLS pure variant columns are first copied into LDS (`st`), which
 // turns the generic kernels' latency-bound row walks into LDS reads.
-constexpr u32 STAGE_COLS = 64;
+constexpr u32 STAGE_COLS = 64;            // variant columns of a segment that are staged at most
+constexpr u32 STAGE_WMAX = 512;           // widest segment (variant + common columns) that is staged
+// staging area: slot_tab[cap] u64 | cmap[STAGE_WMAX] u8 (staged column of segment column c, 0xFF: a common column)
+// | cref[STAGE_WMAX] u8 (its reference byte) | the staged variant columns (pitch Spad)
+__host__ __device__ inline u32 stage_cols_offset(u32 cap) { return (cap * 8u + 2u * STAGE_WMAX + 15u) & ~15u; }
 struct SegCells {
-    const MsaView& mv; u64 a; const uint8_t* st;
+    const MsaView& mv; u64 a; const uint8_t* st; u32 cap;
     __device__ __forceinline__ u32 at(u64 c, u32 r) const
     {
-        if (st) return st[(size_t)(c - a) * mv.Spad + r];
+        if (st && (cap >> 31)) return st[stage_cols_offset(cap & 0xffffu) + (size_t)(c - a) * mv.Spad + r];   // every column staged in place
+        if (st) {                                             // variant columns + column map
+            const u32 i = st[cap * 8u + (u32)(c - a)];
+            return i == 0xffu ? st[cap * 8u + STAGE_WMAX + (u32)(c - a)] : st[stage_cols_offset(cap) + (size_t)i * mv.Spad + r];
+        }
         return mv.vbit(c) ? mv.vc[mv.slot(c) * mv.Spad + r] : mv.ref_byte(c);
     }
 };
-// all threads of the workgroup; returns the LDS image of the segment's columns or nullptr
-__device__ const uint8_t* stage_columns(const MsaView& mv, u64 a, u64 b, uint8_t* buf, u32 cap_cols, u32* flag_sh)
+// all threads of the workgroup; returns the staging area with the segment's cells or nullptr (too wide, or more variant
+// columns than fit).  A segment of at most cap_cols columns is staged column for column (a common column inside - context
+// merge - as a splat of its reference byte; `cap` comes back with bit 31 set: direct indexing); a wider one keeps only its
+// variant columns plus a column map.
+__device__ const uint8_t* stage_columns(const MsaView& mv, u64 a, u64 b, uint8_t* buf, u32& cap, u32* flag_sh)
 {
     const u64 ncol = b - a;
-    if (!buf || ncol > cap_cols) return nullptr;
-    u64* slot_tab = reinterpret_cast<u64*>(buf);              // cap_cols entries, then the columns
-    uint8_t* cols = buf + (size_t)cap_cols * 8;
-    (void)flag_sh;
+    const u32 cap_cols = cap;
+    if (!buf || ncol > STAGE_WMAX) return nullptr;
+    u64* slot_tab = reinterpret_cast<u64*>(buf);
+    if (ncol <= cap_cols) {
+        uint8_t* cols = buf + stage_cols_offset(cap_cols);
+        __syncthreads();                                      // (the previous segment is done with the staging area)
+        if (threadIdx.x < ncol) {
+            const u64 c = a + threadIdx.x;
+            slot_tab[threadIdx.x] = mv.vbit(c) ? mv.slot(c) : ((1ull << 63) | mv.ref_byte(c));
+        }
+        __syncthreads();
+        const u32 vec = mv.Spad / 16;                         // Spad % 16 == 0
+        for (u32 i = threadIdx.x; i < (u32)ncol * vec; i += blockDim.x) {
+            const u32 c = i / vec, o = (i - c * vec) * 16;
+            const u64 sl = slot_tab[c];
+            uint4 v;
+            if (sl >> 63) { const u32 b4 = (u32)(sl & 0xffu) * 0x01010101u; v = make_uint4(b4, b4, b4, b4); }
+            else v = *reinterpret_cast<const uint4*>(mv.vc + sl * (u64)mv.Spad + o);
+            *reinterpret_cast<uint4*>(cols + (size_t)c * mv.Spad + o) = v;
+        }
+        __syncthreads();
+        cap = cap_cols | 0x80000000u;
+        return buf;
+    }
+    uint8_t* cmap = buf + cap_cols * 8u;
+    uint8_t* cref = cmap + STAGE_WMAX;
+    uint8_t* cols = buf + stage_cols_offset(cap_cols);
     __syncthreads();                                          // (the previous segment is done with the staging area)
-    if (threadIdx.x < ncol) {
-        const u64 c = a + threadIdx.x;
-        // a common column inside (context merge): every row has the reference byte there
-        slot_tab[threadIdx.x] = mv.vbit(c) ? mv.slot(c) : ((1ull << 63) | mv.ref_byte(c));
+    if (threadIdx.x == 0) *flag_sh = 0;
+    __syncthreads();
+    for (u32 c = threadIdx.x; c < (u32)ncol; c += blockDim.x) {
+        if (mv.vbit(a + c)) {
+            const u32 idx = atomicAdd(flag_sh, 1u);
+            if (idx < cap_cols) { slot_tab[idx] = mv.slot(a + c); cmap[c] = (uint8_t)idx; }
+        } else { cmap[c] = 0xff; cref[c] = (uint8_t)mv.ref_byte(a + c); }
     }
     __syncthreads();
+    const u32 nvar = *flag_sh;
+    if (nvar > cap_cols) return nullptr;                      // (workgroup-uniform)
     const u32 vec = mv.Spad / 16;                             // Spad % 16 == 0
-    for (u32 i = threadIdx.x; i < (u32)ncol * vec; i += blockDim.x) {
+    for (u32 i = threadIdx.x; i < nvar * vec; i += blockDim.x) {
         const u32 c = i / vec, o = (i - c * vec) * 16;
-        const u64 sl = slot_tab[c];
-        uint4 v;
-        if (sl >> 63) { const u32 b4 = (u32)(sl & 0xffu) * 0x01010101u; v = make_uint4(b4, b4, b4, b4); }
-        else v = *reinterpret_cast<const uint4*>(mv.vc + sl * (u64)mv.Spad + o);
-        *reinterpret_cast<uint4*>(cols + (size_t)c * mv.Spad + o) = v;
+        *reinterpret_cast<uint4*>(cols + (size_t)c * mv.Spad + o) =
+            *reinterpret_cast<const uint4*>(mv.vc + slot_tab[c] * (u64)mv.Spad + o);
     }
     __syncthreads();
-    return cols;
+    return buf;
 }
 
 // gap-stripped string of row r over [a,b): the reference drops '\n' and '-' and stops at '\0'
@@ -1312,10 +1348,10 @@ struct HtLds {
 };
 
 // returns k (number of distinct strings); fills lds.gid[], lds.rep_row[0..k)
-__device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* rep_sh, const uint8_t* st)
+__device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* rep_sh, const uint8_t* st, u32 cap)
 {
     const u32 S = mv.S;
-    const SegCells sc{mv, a, st};
+    const SegCells sc{mv, a, st, cap};
     const bool exact = (b - a) <= 8;
     u32 saw_nl = 0;
     for (u32 r = threadIdx.x; r < S; r += GT) {
@@ -1432,8 +1468,9 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
             continue;
         }
         if (threadIdx.x == 0) sum_sh = 0;
-        const uint8_t* st = stage_columns(p.mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, p.stage_cols, &rep_sh);
-        const u32 k = group_segment(p.mv, a, b, lds, &rep_sh, st);
+        u32 cap = p.stage_cols;
+        const uint8_t* st = stage_columns(p.mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, cap, &rep_sh);
+        const u32 k = group_segment(p.mv, a, b, lds, &rep_sh, st, cap);
         if (it < p.gcache_cap) {                             // the emitter takes the grouping from here
             uint8_t* ce = p.gcache + it * (u64)p.gcache_stride;
             uint16_t* cg = reinterpret_cast<uint16_t*>(ce + 16);
@@ -1442,7 +1479,7 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
             for (u32 r = threadIdx.x; r < p.mv.S; r += GT) cg[r] = lds.gid[r];
             for (u32 g = threadIdx.x; g < k; g += GT) cr[g] = lds.rep_row[g];
         }
-        const SegCells sc{p.mv, a, st};
+        const SegCells sc{p.mv, a, st, cap};
         u64 mine = 0;
         for (u32 g = threadIdx.x; g < k; g += GT) mine += seg_row_len(sc, a, b, lds.rep_row[g]);
         if (mine) atomicAdd(&sum_sh, mine);
@@ -1514,7 +1551,8 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
         const u64 seg = p.list ? p.list[it] : it;
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         if (!mv.vbit(a)) continue;
-        const uint8_t* st = stage_columns(mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, p.stage_cols, &rep_sh);
+        u32 cap = p.stage_cols;
+        const uint8_t* st = stage_columns(mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, cap, &rep_sh);
         u32 k;
         if (it < p.gcache_cap) {                             // grouped by k_seg_count already
             const uint8_t* ce = p.gcache + it * (u64)p.gcache_stride;
@@ -1525,8 +1563,8 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
             for (u32 r = threadIdx.x; r < S; r += GT) lds.gid[r] = cg[r];
             for (u32 g = threadIdx.x; g < k; g += GT) lds.rep_row[g] = cr[g];
             __syncthreads();
-        } else k = group_segment(mv, a, b, lds, &rep_sh, st);
-        const SegCells sc{mv, a, st};
+        } else k = group_segment(mv, a, b, lds, &rep_sh, st, cap);
+        const SegCells sc{mv, a, st, cap};
         uint8_t* eds = p.eds + p.eds_off[seg];
         uint8_t* seds = p.seds + p.seds_off[seg];
 
@@ -3074,10 +3112,11 @@ void MsaPipeline::plan_body(hipStream_t st)
     stage_cols_ = 0;
     {                                                     // as many columns of a segment as fit beside that (<= STAGE_COLS)
         const size_t budget = (size_t)150 * 1024;
-        if (seg_lds_ + 4 * ((size_t)Spad + 8) <= budget) {
-            stage_cols_ = (u32)std::min<size_t>(STAGE_COLS, (budget - seg_lds_) / ((size_t)Spad + 8));
+        const size_t maps = 2 * (size_t)STAGE_WMAX + 16;     // column map + reference bytes of the common columns
+        if (seg_lds_ + maps + 4 * ((size_t)Spad + 8) <= budget) {
+            stage_cols_ = (u32)std::min<size_t>(STAGE_COLS, (budget - seg_lds_ - maps) / ((size_t)Spad + 8));
             stage_off_ = (u32)seg_lds_;
-            seg_lds_ += (size_t)stage_cols_ * 8 + (size_t)stage_cols_ * Spad;
+            seg_lds_ += stage_cols_offset(stage_cols_) + (size_t)stage_cols_ * Spad;
         }
     }
 
