@@ -1333,18 +1333,21 @@ __device__ u32 seg_row_len(const SegCells& sc, u64 a, u64 b, u32 r)
 // (the iterative path below needs one barrier round per distinct string).  Hashed keys are verified
 // byte for byte against the group's first row; a collision falls back to the iterative path.
 constexpr u32 HT_MAX_ROWS = 2048, HT_SIZE = 4096;
+// table entries for S rows: twice the rows, a power of two (1024 rows -> 2048 entries: two workgroups fit a CU)
+__host__ __device__ inline u32 ht_size_of(u32 S) { u32 n = 256; while (n < 2u * S) n <<= 1; return n < HT_SIZE ? n : HT_SIZE; }
 constexpr u64 HT_EMPTY = ~0ull;
 struct HtLds {
     u64* tabk; u32* tabm; u32* bm; u32* pre; u32* flag;
-    __device__ HtLds(uint8_t* base)
+    __device__ HtLds(uint8_t* base, u32 hsz)
     {
         tabk = reinterpret_cast<u64*>(base);
-        tabm = reinterpret_cast<u32*>(base + (size_t)8 * HT_SIZE);
-        bm = reinterpret_cast<u32*>(base + (size_t)12 * HT_SIZE);
+        tabm = reinterpret_cast<u32*>(base + (size_t)8 * hsz);
+        bm = reinterpret_cast<u32*>(base + (size_t)12 * hsz);
         pre = bm + 72;
         flag = pre + 72;
     }
     static constexpr size_t BYTES = (size_t)12 * HT_SIZE + 4 * (72 + 72 + 8);
+    __host__ __device__ static size_t bytes(u32 hsz) { return (size_t)12 * hsz + 4 * (72 + 72 + 8); }
 };
 
 // returns k (number of distinct strings); fills lds.gid[], lds.rep_row[0..k)
@@ -1361,19 +1364,20 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
     if (saw_nl) atomicOr(&mv.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));   // a row is ragged
 
     if (S <= HT_MAX_ROWS) {
-        HtLds ht(reinterpret_cast<uint8_t*>(lds.gid + ((S + 7) & ~7u)));
-        for (u32 i = threadIdx.x; i < HT_SIZE; i += GT) { ht.tabk[i] = HT_EMPTY; ht.tabm[i] = 0xffffffffu; }
+        const u32 hsz = ht_size_of(S);
+        HtLds ht(reinterpret_cast<uint8_t*>(lds.gid + ((S + 7) & ~7u)), hsz);
+        for (u32 i = threadIdx.x; i < hsz; i += GT) { ht.tabk[i] = HT_EMPTY; ht.tabm[i] = 0xffffffffu; }
         for (u32 i = threadIdx.x; i < 72; i += GT) ht.bm[i] = 0;
         if (threadIdx.x == 0) *ht.flag = 0;
         __syncthreads();
         for (u32 r = threadIdx.x; r < S; r += GT) {
             u64 kk = lds.key[r];
             if (kk == HT_EMPTY) kk = HT_EMPTY - 1;
-            u32 slot = (u32)(mix64(kk) >> 20) & (HT_SIZE - 1);
+            u32 slot = (u32)(mix64(kk) >> 20) & (hsz - 1);
             while (true) {
                 const u64 cur = atomicCAS(&ht.tabk[slot], HT_EMPTY, kk);
                 if (cur == HT_EMPTY || cur == kk) { atomicMin(&ht.tabm[slot], r); lds.run[r] = slot; break; }
-                slot = (slot + 1) & (HT_SIZE - 1);
+                slot = (slot + 1) & (hsz - 1);
             }
         }
         __syncthreads();
@@ -3106,15 +3110,20 @@ void MsaPipeline::plan_body(hipStream_t st)
     mv_.word_slot = wslot_.as<u64>(); mv_.vc = vc_.as<uint8_t>(); mv_.hdr = dh; mv_.L = L; mv_.lw = lw;
     mv_.S = (u32)S; mv_.Spad = Spad; mv_.tileW = (u32)W;
     seg_start_p_ = seg_start; hseg_p_ = Hseg; segbase_p_ = segbase; nseg_p_ = d_nseg;
-    seg_lds_ = (size_t)18 * S + 64 + (S <= HT_MAX_ROWS ? HtLds::BYTES + 16 : 0);
+    seg_lds_ = (size_t)18 * S + 64 + (S <= HT_MAX_ROWS ? HtLds::bytes(ht_size_of((u32)S)) + 16 : 0);
     seg_lds_ = (seg_lds_ + 15) & ~(size_t)15;
     stage_off_ = 0;
     stage_cols_ = 0;
     {                                                     // as many columns of a segment as fit beside that (<= STAGE_COLS)
         const size_t budget = (size_t)150 * 1024;
         const size_t maps = 2 * (size_t)STAGE_WMAX + 16;     // column map + reference bytes of the common columns
-        if (seg_lds_ + maps + 4 * ((size_t)Spad + 8) <= budget) {
-            stage_cols_ = (u32)std::min<size_t>(STAGE_COLS, (budget - seg_lds_ - maps) / ((size_t)Spad + 8));
+        static int two_env = -1;
+        if (two_env < 0) { const char* e = getenv("EDSX_GEN2"); two_env = e ? atoi(e) : 1; }
+        const size_t half = (size_t)74 * 1024;               // two workgroups per CU if 24 columns and more still fit (wider
+        size_t use = budget;                                 // segments keep their variant columns + a column map)
+        if (two_env && seg_lds_ + maps + 24 * ((size_t)Spad + 8) <= half) use = half;
+        if (seg_lds_ + maps + 4 * ((size_t)Spad + 8) <= use) {
+            stage_cols_ = (u32)std::min<size_t>(STAGE_COLS, (use - seg_lds_ - maps) / ((size_t)Spad + 8));
             stage_off_ = (u32)seg_lds_;
             seg_lds_ += stage_cols_offset(stage_cols_) + (size_t)stage_cols_ * Spad;
         }
