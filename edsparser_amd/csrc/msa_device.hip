@@ -1942,7 +1942,7 @@ __device__ __forceinline__ int refine_groups(LoadCol load_col, Cell cell, u32 nc
     u32 lut[MAXG / 4];                                  // raw group -> final group
 #pragma unroll
     for (int i = 0; i < MAXG / 4; i++) lut[i] = 0;
-    u32 nroot = 0, sumlen = 0, root_len_l = 0, root_slot_l = 0, root_rep_l = 0;   // lane t: root t
+    u32 nroot = 0, sumlen = 0, root_len_l = 0, root_slot_l = 0, root_rep_l = 0, root_hash_l = 0;   // lane t: root t
     for (u32 r = 0; r < k; r++) {
         const u32 gs = (u32)__builtin_ctzll(ballot64(lane < k && rank_l == r));
         const u32 row = (u32)__builtin_amdgcn_readlane((int)rep_l, (int)gs);
@@ -1955,16 +1955,18 @@ __device__ __forceinline__ int refine_groups(LoadCol load_col, Cell cell, u32 nc
         const u64 nz = ballot64(keep);
         const u32 len = (u32)__builtin_popcountll(nz);
         if (keep) strs[r * 64u + mbcnt(nz)] = (uint8_t)c;
-        // the same string as an earlier root?
+        // the same string as an earlier root?  Candidates by length and a hash of the letters in their columns (one
+        // ballot instead of a walk over the roots: wide segments of an l-EDS have tens of raw groups), then the letters.
+        const u32 hsh = wave_xor_all(keep ? (c + 1u) * (0x9e3779b1u + 0x85ebca77u * mbcnt(nz)) : 0u);
         u32 fin = nroot;
-        for (u32 tt = 0; tt < nroot; tt++) {
-            if ((u32)__builtin_amdgcn_readlane((int)root_len_l, (int)tt) != len) continue;
+        for (u64 cand = ballot64(lane < nroot && root_len_l == len && root_hash_l == hsh); cand; cand &= cand - 1) {
+            const u32 tt = (u32)__builtin_ctzll(cand);
             const u32 sl = (u32)__builtin_amdgcn_readlane((int)root_slot_l, (int)tt);
             const bool diff = lane < len && strs[r * 64u + lane] != strs[sl * 64u + lane];
             if (!ballot64(diff)) { fin = tt; break; }
         }
         if (fin == nroot) {
-            if (lane == nroot) { root_len_l = len; root_slot_l = r; root_rep_l = row; }
+            if (lane == nroot) { root_len_l = len; root_slot_l = r; root_rep_l = row; root_hash_l = hsh; }
             nroot++; sumlen += len;
         }
         // lut[gs >> 2] |= fin << ...  (static indices only: registers)
