@@ -1335,19 +1335,18 @@ __device__ u32 seg_row_len(const SegCells& sc, u64 a, u64 b, u32 r)
 constexpr u32 HT_MAX_ROWS = 2048, HT_SIZE = 4096;
 // table entries for S rows: twice the rows, a power of two (1024 rows -> 2048 entries: two workgroups fit a CU)
 __host__ __device__ inline u32 ht_size_of(u32 S) { u32 n = 256; while (n < 2u * S) n <<= 1; return n < HT_SIZE ? n : HT_SIZE; }
-constexpr u64 HT_EMPTY = ~0ull;
+// one u32 per entry: while the rows insert themselves it holds the row that claimed the entry (keys are compared through
+// lds.key[]), afterwards the first row of the entry's string
 struct HtLds {
-    u64* tabk; u32* tabm; u32* bm; u32* pre; u32* flag;
+    u32* tabm; u32* bm; u32* pre; u32* flag;
     __device__ HtLds(uint8_t* base, u32 hsz)
     {
-        tabk = reinterpret_cast<u64*>(base);
-        tabm = reinterpret_cast<u32*>(base + (size_t)8 * hsz);
-        bm = reinterpret_cast<u32*>(base + (size_t)12 * hsz);
+        tabm = reinterpret_cast<u32*>(base);
+        bm = reinterpret_cast<u32*>(base + (size_t)4 * hsz);
         pre = bm + 72;
         flag = pre + 72;
     }
-    static constexpr size_t BYTES = (size_t)12 * HT_SIZE + 4 * (72 + 72 + 8);
-    __host__ __device__ static size_t bytes(u32 hsz) { return (size_t)12 * hsz + 4 * (72 + 72 + 8); }
+    __host__ __device__ static size_t bytes(u32 hsz) { return (size_t)4 * hsz + 4 * (72 + 72 + 8); }
 };
 
 // returns k (number of distinct strings); fills lds.gid[], lds.rep_row[0..k)
@@ -1366,20 +1365,23 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
     if (S <= HT_MAX_ROWS) {
         const u32 hsz = ht_size_of(S);
         HtLds ht(reinterpret_cast<uint8_t*>(lds.gid + ((S + 7) & ~7u)), hsz);
-        for (u32 i = threadIdx.x; i < hsz; i += GT) { ht.tabk[i] = HT_EMPTY; ht.tabm[i] = 0xffffffffu; }
+        for (u32 i = threadIdx.x; i < hsz; i += GT) ht.tabm[i] = 0xffffffffu;
         for (u32 i = threadIdx.x; i < 72; i += GT) ht.bm[i] = 0;
         if (threadIdx.x == 0) *ht.flag = 0;
         __syncthreads();
         for (u32 r = threadIdx.x; r < S; r += GT) {
-            u64 kk = lds.key[r];
-            if (kk == HT_EMPTY) kk = HT_EMPTY - 1;
+            const u64 kk = lds.key[r];
             u32 slot = (u32)(mix64(kk) >> 20) & (hsz - 1);
             while (true) {
-                const u64 cur = atomicCAS(&ht.tabk[slot], HT_EMPTY, kk);
-                if (cur == HT_EMPTY || cur == kk) { atomicMin(&ht.tabm[slot], r); lds.run[r] = slot; break; }
+                const u32 cur = atomicCAS(&ht.tabm[slot], 0xffffffffu, r);
+                if (cur == 0xffffffffu || lds.key[cur] == kk) { lds.run[r] = slot; break; }
                 slot = (slot + 1) & (hsz - 1);
             }
         }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < hsz; i += GT) ht.tabm[i] = 0xffffffffu;
+        __syncthreads();
+        for (u32 r = threadIdx.x; r < S; r += GT) atomicMin(&ht.tabm[lds.run[r]], r);
         __syncthreads();
         for (u32 r = threadIdx.x; r < S; r += GT) {
             const u32 f = ht.tabm[lds.run[r]];
@@ -3121,9 +3123,18 @@ void MsaPipeline::plan_body(hipStream_t st)
         const size_t maps = 2 * (size_t)STAGE_WMAX + 16;     // column map + reference bytes of the common columns
         static int two_env = -1;
         if (two_env < 0) { const char* e = getenv("EDSX_GEN2"); two_env = e ? atoi(e) : 1; }
-        const size_t half = (size_t)74 * 1024;               // two workgroups per CU if 24 columns and more still fit (wider
-        size_t use = budget;                                 // segments keep their variant columns + a column map)
-        if (two_env && seg_lds_ + maps + 24 * ((size_t)Spad + 8) <= half) use = half;
+        static int mincol_env = -1;
+        if (mincol_env < 0) { const char* e = getenv("EDSX_GEN_MINCOLS"); mincol_env = e ? atoi(e) : 24; }
+        // two (or three) workgroups per CU if 24 columns and more still fit - 8 for more than 1024 rows, which have no other
+        // path (wider segments keep their variant columns + a column map)
+        const size_t nblk = (S + 63) / 64, S2 = (S + 1) & ~(size_t)1;
+        const size_t walk_cols = (nblk * 384 + S2 * 3 + nblk + 16 + Spad + 7) / ((size_t)Spad + 8);     // the emitter's tables for the .seds walk live there too
+        const size_t mincols = S > 1024 ? std::max<size_t>(8, walk_cols) : (size_t)mincol_env;
+        size_t use = budget;
+        for (int n = two_env > 1 ? two_env : 2; n >= 2 && two_env; n--) {
+            const size_t part = (size_t)(150 / n - 1) * 1024;
+            if (seg_lds_ + maps + mincols * ((size_t)Spad + 8) <= part) { use = part; break; }
+        }
         if (seg_lds_ + maps + 4 * ((size_t)Spad + 8) <= use) {
             stage_cols_ = (u32)std::min<size_t>(STAGE_COLS, (use - seg_lds_ - maps) / ((size_t)Spad + 8));
             stage_off_ = (u32)seg_lds_;
