@@ -1178,7 +1178,7 @@ __global__ void k_popc_words(const u64* __restrict__ H, u64* __restrict__ cnt, u
 // Workgroup-level (GT threads).  LDS carve (18 bytes per row):
 //   key[S] u64 | rep_row[S] u32 | run[S] u32 | gid[S] u16
 // ---------------------------------------------------------------------------------------------
-constexpr int GT = 256;
+constexpr int GT = 512;
 constexpr u32 GID_NONE = 0xffffu;
 
 struct SegLds {
@@ -1204,10 +1204,14 @@ struct SegCells {
     const MsaView& mv; u64 a; const uint8_t* st; u32 cap;
     __device__ __forceinline__ u32 at(u64 c, u32 r) const
     {
-        if (st && (cap >> 31)) return st[stage_cols_offset(cap & 0xffffu) + (size_t)(c - a) * mv.Spad + r];   // every column staged in place
+        // (the staging area is LDS: an explicit LDS pointer, or the reads become flat loads - `st` is a select of an LDS
+        // address and nullptr, whose address space the compiler does not follow)
+        typedef const __attribute__((address_space(3))) uint8_t* lds_bytes;
+        if (st && (cap >> 31)) return ((lds_bytes)st)[stage_cols_offset(cap & 0xffffu) + (u32)(c - a) * mv.Spad + r];   // every column staged in place
         if (st) {                                             // variant columns + column map
-            const u32 i = st[cap * 8u + (u32)(c - a)];
-            return i == 0xffu ? st[cap * 8u + STAGE_WMAX + (u32)(c - a)] : st[stage_cols_offset(cap) + (size_t)i * mv.Spad + r];
+            const lds_bytes sl = (lds_bytes)st;
+            const u32 i = sl[cap * 8u + (u32)(c - a)];
+            return i == 0xffu ? sl[cap * 8u + STAGE_WMAX + (u32)(c - a)] : sl[stage_cols_offset(cap) + i * mv.Spad + r];
         }
         return mv.vbit(c) ? mv.vc[mv.slot(c) * mv.Spad + r] : mv.ref_byte(c);
     }
@@ -1465,14 +1469,18 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
     __shared__ u64 sum_sh;
     SegLds lds(lds_raw, p.mv.S);
     if (p.mv.hdr->status) return;                     // vc overflow: the host grows vc and replans
-    const u64 nitems = p.list ? *p.list_n : *p.nseg_ptr;
-    for (u64 it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const u64 seg = p.list ? p.list[it] : it;
-        const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
-        if (!p.mv.vbit(a)) {
-            if (threadIdx.x == 0) { p.eds_len[seg] = 2 + (b - a); p.seds_len[seg] = 3; }
-            continue;
+    // without a work list: every segment.  Variant and common segments alternate (item `it` = the it-th variant segment);
+    // the common ones are a thread each
+    const u64 nseg = *p.nseg_ptr, p0 = p.mv.vbit(0) ? 0 : 1;
+    if (!p.list)
+        for (u64 seg = (1 - p0) + 2 * (blockIdx.x * (u64)GT + threadIdx.x); seg < nseg; seg += 2 * (u64)gridDim.x * GT) {
+            p.eds_len[seg] = 2 + (p.seg_start[seg + 1] - p.seg_start[seg]);
+            p.seds_len[seg] = 3;
         }
+    const u64 nitems = p.list ? *p.list_n : (nseg > p0 ? (nseg - p0 + 1) / 2 : 0);
+    for (u64 it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const u64 seg = p.list ? p.list[it] : p0 + 2 * it;
+        const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         if (threadIdx.x == 0) sum_sh = 0;
         u32 cap = p.stage_cols;
         const uint8_t* st = stage_columns(p.mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, cap, &rep_sh);
@@ -1551,12 +1559,12 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
     const u32 S = mv.S;
     SegLds lds(lds_raw, S);
     if (mv.hdr->status) return;
-    const u64 nitems = p.list ? *p.list_n : *p.nseg_ptr;
+    const u64 nseg = *p.nseg_ptr, p0 = mv.vbit(0) ? 0 : 1;      // items as in k_seg_count
+    const u64 nitems = p.list ? *p.list_n : (nseg > p0 ? (nseg - p0 + 1) / 2 : 0);
     const u32 lane = threadIdx.x & 63;
     for (u64 it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const u64 seg = p.list ? p.list[it] : it;
+        const u64 seg = p.list ? p.list[it] : p0 + 2 * it;
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
-        if (!mv.vbit(a)) continue;
         u32 cap = p.stage_cols;
         const uint8_t* st = stage_columns(mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, cap, &rep_sh);
         u32 k;
