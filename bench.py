@@ -43,6 +43,8 @@ def parse_args():
                     help="size of the CPU-baseline sample in MB (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: take the multi-rank code path (process group, stitch, reductions) with WORLD_SIZE=1 too")
     ap.add_argument("--verify", type=int, default=1,
                     help="N=1, context length 0: after the timed region compare sampled column windows of the outputs "
                          "(spread over the whole width, incl. offsets beyond 4 GiB and the last columns) with the CPU "
@@ -98,8 +100,9 @@ def main():
         sys.exit(2)
     if a.share_gpu:
         local_rank = 0
+    distributed = world > 1 or a.force_dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if distributed:
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -120,7 +123,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     stitcher = None
-    if world > 1:
+    if distributed:
         # boundary-segment stitch: KB-sized all_gather_object exchanges over RCCL (nccl backend)
         from edsparser_amd.multigpu import gpu_stitcher
         stitcher = gpu_stitcher(ctx, edsparser_amd.Context(local_rank), rank, world, S, L, dist)
@@ -144,20 +147,20 @@ def main():
     torch.cuda.synchronize()
     if not os.environ.get("EDSX_BENCH_NOTIMING"):
         ctx.set_timing(True)
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
     timing = ctx.get_timing()
     ctx.set_timing(False)
     n_total = float(n)
-    if world > 1:
+    if distributed:
         dev = "cuda" if a.backend == "nccl" else "cpu"
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,12 +227,12 @@ def main():
                        "segments": info["n_segments"], "variant_cols": info["n_variant_cols"],
                        "slow_segments": info["n_slow_segments"],
                        "partition": "columns x %d" % world,
-                       "stitch": (out.get("stitch") or {}).get("chains") if world > 1 else None},
+                       "stitch": (out.get("stitch") or {}).get("chains") if distributed else None},
             "frac_of_hbm_read_roofline": round(value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4),
             "roofline": roof, "cpu_baseline": cpu, "verify": verify, "kernel_ms": per_kernel,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
