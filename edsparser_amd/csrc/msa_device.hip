@@ -1272,25 +1272,6 @@ __device__ const uint8_t* stage_columns(const MsaView& mv, u64 a, u64 b, uint8_t
     return buf;
 }
 
-// gap-stripped string of row r over [a,b): the reference drops '\n' and '-' and stops at '\0'
-// (msa_transforms.cpp:281-286)
-__device__ u64 seg_row_key(const SegCells& sc, u64 a, u64 b, u32 r, bool exact, u32& saw_nl)
-{
-    u64 key = exact ? 0ull : 0xcbf29ce484222325ull;
-    u32 len = 0;
-    for (u64 c = a; c < b; c++) {
-        u32 ch = sc.at(c, r);
-        if (ch == 0) break;
-        if (ch == '\n') saw_nl = 1;
-        if (ch == '-' || ch == '\n') continue;
-        if (exact) key |= (u64)ch << (8 * len);
-        else key = (key ^ ch) * 0x100000001b3ull;
-        len++;
-    }
-    if (!exact) key = (key ^ len) * 0x100000001b3ull;
-    return key;
-}
-
 // Do rows r1 and r2 spell the same gap-stripped string over [a,b)?  Written for a wave whose lanes
 // compare different row pairs: the common case (the two rows are byte-identical) is one pass with no
 // data-dependent branch; otherwise one merged two-pointer loop in which every lane advances at least
@@ -1360,10 +1341,45 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
     const SegCells sc{mv, a, st, cap};
     const bool exact = (b - a) <= 8;
     u32 saw_nl = 0;
-    for (u32 r = threadIdx.x; r < S; r += GT) {
-        lds.key[r] = seg_row_key(sc, a, b, r, exact, saw_nl);
-        lds.gid[r] = GID_NONE;
-    }
+    // keys of R rows per thread side by side, column by column (R = 1, 2 or 4 by the row count): no branch depends on a
+    // cell (what a column is - staged, mapped, a common column's reference byte - is decided once per column for the R
+    // rows; '-', '\n' and the end of a row at '\0' are selects), where a loop per row with its `break` ran ~80 mostly
+    // scalar instructions per cell
+    auto make_keys = [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        for (u32 r0 = threadIdx.x; r0 < S; r0 += R * GT) {
+            u32 rr[R], len[R], ended[R];
+            u64 key[R];
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                const u32 r = r0 + (u32)i * GT;
+                rr[i] = r < S ? r : S - 1; len[i] = 0; ended[i] = 0; key[i] = exact ? 0ull : 0xcbf29ce484222325ull;
+            }
+            for (u64 c = a; c < b; c++) {
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const u32 ch = sc.at(c, rr[i]);
+                    ended[i] |= ch == 0 ? 1u : 0u;             // '\0' ends the row (msa_transforms.cpp:282)
+                    const bool nl = ch == '\n', keep = !ended[i] && ch != '-' && !nl;
+                    saw_nl |= (nl && !ended[i]) ? 1u : 0u;
+                    if (exact) key[i] |= keep ? (u64)ch << (8 * len[i]) : 0ull;
+                    else key[i] = keep ? (key[i] ^ ch) * 0x100000001b3ull : key[i];
+                    len[i] += keep ? 1u : 0u;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                const u32 r = r0 + (u32)i * GT;
+                if (r < S) {
+                    lds.key[r] = exact ? key[i] : (key[i] ^ len[i]) * 0x100000001b3ull;
+                    lds.gid[r] = GID_NONE;
+                }
+            }
+        }
+    };
+    if (S <= (u32)GT) make_keys(std::integral_constant<int, 1>{});
+    else if (S <= 2u * GT) make_keys(std::integral_constant<int, 2>{});
+    else make_keys(std::integral_constant<int, 4>{});
     if (saw_nl) atomicOr(&mv.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));   // a row is ragged
 
     if (S <= HT_MAX_ROWS) {
