@@ -1411,16 +1411,12 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
         }
         __syncthreads();
         if (*ht.flag == 0) {
-            const u32 nwords = (S + 31) >> 5;
-            if (threadIdx.x < nwords) {
-                u32 acc = 0;
-                for (u32 w = 0; w < threadIdx.x; w++) acc += __builtin_popcount(ht.bm[w]);
-                ht.pre[threadIdx.x] = acc;
-            }
-            if (threadIdx.x == 0) {
-                u32 acc = 0;
-                for (u32 w = 0; w < nwords; w++) acc += __builtin_popcount(ht.bm[w]);
-                *rep_sh = acc;
+            const u32 nwords = (S + 31) >> 5;                 // <= 64: one wave scans the first-row counts of the words
+            if (threadIdx.x < 64) {
+                const u32 c = threadIdx.x < nwords ? (u32)__builtin_popcount(ht.bm[threadIdx.x]) : 0u;
+                const u32 incl = wave_scan_incl(c);
+                if (threadIdx.x < nwords) ht.pre[threadIdx.x] = incl - c;
+                if (threadIdx.x == 63) *rep_sh = incl;
             }
             __syncthreads();
             u32 myg[HT_MAX_ROWS / GT];
