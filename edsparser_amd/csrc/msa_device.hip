@@ -1628,8 +1628,8 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
         __syncthreads();
 
         // ---- seds: run[g] = next write offset of group g.  A row's token goes behind the tokens of the earlier rows of its
-        // group.  When the staging area (free again: the .eds text is written) holds the tables, all four waves work on
-        // it: (A) every wave takes every fourth 64-row block and finds, per distinct group of the block, the bytes of its
+        // group.  When the staging area (free again: the .eds text is written) holds the tables, all waves of the workgroup work on
+        // it: (A) every wave takes its share of the 64-row blocks and finds, per distinct group of the block, the bytes of its
         // rows and every row's offset among them; (B) wave 0 walks the blocks in order and turns the per-block group
         // totals into start offsets (a block's groups are distinct: one lane each); (C) all waves store their tokens.
         // Otherwise (no staging area: very many rows) wave 0 walks the rows block by block.
