@@ -197,55 +197,167 @@ __global__ void k_fin_list(FinParams p)
     }
 }
 
-// one thread per final string: walk the entry tree left to right and copy the leaf strings
-__global__ void k_fin_write(FinParams p, u64 nstr)
+// ---- final text ---------------------------------------------------------------------------------------
+// A string of the result is the left-to-right concatenation of the leaves of its entry's merge tree.  Walking that tree
+// with one thread per string is a chain of dependent loads as long as the string has leaves (l = 32 on a 10 % EDS:
+// strings of several hundred leaves, 1.8 ms for the longest one alone).  Every entry carries its length, so a node's
+// output offset follows from its parent's (right child = offset + length of the left one) and the subtrees can be
+// expanded side by side: a workgroup takes a batch of `ns` consecutive strings, keeps (entry, offset) items on a stack
+// in LDS, and in every round each thread pops one item - a leaf is copied to its place, an inner entry pushes its two
+// children (empty subtrees are dropped, so the items of one level cover disjoint bytes).  The latency per string is its
+// tree's depth, not its number of leaves.  Leaves of 256 bytes and more are copied by the whole workgroup.  A stack that
+// would overflow (far beyond 256 x depth items) sends the batch to the serial walk below, which also has the only
+// depth limit left.
+constexpr u32 FW_STACK = 4096, FW_LONG = 32, FW_LONG_MIN = 256;
+
+// Depth of an entry's merge tree <= number of rounds its symbol took part in.  Every round merges at least half
+// of each run of mergeable pairs (greedy non-overlapping pairs, eds_transforms.cpp:63-66), so a symbol built from
+// 2^32 leaves - more than the pool can hold - is at most ~33 levels deep plus the rounds in which a product
+// collapsed and reopened a run; 96 is far beyond what fits in the 32-bit entry pool.  An overflow still raises.
+constexpr int FIN_STACK = 96;
+
+// the serial walk: one thread, one string (fallback of k_fin_write)
+__device__ void fin_eds_direct(const FinParams& p, u64 t)
 {
-    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < nstr; t += (u64)gridDim.x * blockDim.x) {
-        const uint8_t fl = p.fin_flag[t];
-        uint8_t* o = p.out + p.bytes[t];
-        {   // opening bracket of the symbol's first string, else the separator (kept branch-free:
-            // hipcc 7.2 lost the pointer increment when this was written as nested ifs)
+    const uint8_t fl = p.fin_flag[t];
+    uint8_t* o = p.out + p.bytes[t];
+    {   // opening bracket of the symbol's first string, else the separator (kept branch-free:
+        // hipcc 7.2 lost the pointer increment when this was written as nested ifs)
+        const bool first = (fl & 1) != 0, wr = !first || (fl & 4) != 0;
+        if (wr) *o = first ? '{' : ',';
+        o += wr ? 1 : 0;
+    }
+    u32 stack[FIN_STACK];
+    int sp = 0;
+    stack[sp++] = p.fin_ent[t];
+    while (sp) {
+        const u32 e = stack[--sp];
+        if (p.pool.left[e] == LEAF) {
+            const u64 s0 = p.str_off[p.pool.right[e]], s1 = p.str_off[p.pool.right[e] + 1];
+            for (u64 c = s0; c < s1; c++) *o++ = p.chars[c];
+        } else {
+            if (sp + 2 > FIN_STACK) { *p.err = 1; break; }
+            stack[sp++] = p.pool.right[e];
+            stack[sp++] = p.pool.left[e];
+        }
+    }
+    if ((fl & 2) && (fl & 4)) *o++ = '}';
+}
+
+// n bytes, any alignment, 16 at a time
+__device__ __forceinline__ void fin_copy(uint8_t* dst, const uint8_t* src, u64 n)
+{
+    u64 i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const uint4 v = load16u(src + i);
+        U128u w{v.x, v.y, v.z, v.w};
+        __builtin_memcpy(dst + i, &w, 16);
+    }
+    for (; i < n; i++) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(256) k_fin_write(FinParams p, u64 nstr, u64 E, u32 ns)
+{
+    __shared__ u32 s_ent[FW_STACK];
+    __shared__ u32 s_dst[FW_STACK];                    // offset from the batch's first byte
+    __shared__ u64 l_src[FW_LONG];
+    __shared__ u32 l_dst[FW_LONG], l_len[FW_LONG];
+    __shared__ u32 top, nlong, ovf;
+    const u32 tid = threadIdx.x;
+    const u64 nbatch = (nstr + ns - 1) / ns;
+    for (u64 bt = blockIdx.x; bt < nbatch; bt += gridDim.x) {
+        const u64 t0 = bt * ns, t = t0 + tid;
+        const bool owner = tid < ns && t < nstr;
+        const u64 g0 = p.bytes[t0], g1 = t0 + ns < nstr ? p.bytes[t0 + ns] : E;
+        uint8_t* gout = p.out + g0;
+        __syncthreads();                                   // (the previous batch is done with the stack)
+        if (tid == 0) { top = 0; nlong = 0; ovf = g1 - g0 > 0xffffffffull ? 1u : 0u; }
+        __syncthreads();
+        if (owner && !ovf) {
+            const uint8_t fl = p.fin_flag[t];
+            u32 o = (u32)(p.bytes[t] - g0);
             const bool first = (fl & 1) != 0, wr = !first || (fl & 4) != 0;
-            if (wr) *o = first ? '{' : ',';
-            o += wr ? 1 : 0;
+            if (wr) gout[o] = first ? '{' : ',';
+            o += wr ? 1u : 0u;
+            const u32 e = p.fin_ent[t], len = p.pool.elen[e];
+            if (len) { const u32 slot = atomicAdd(&top, 1u); s_ent[slot] = e; s_dst[slot] = o; }   // ns <= 256 < FW_STACK
+            if ((fl & 2) && (fl & 4)) gout[o + len] = '}';
         }
-        // Depth of an entry's merge tree <= number of rounds its symbol took part in.  Every round merges at least half
-        // of each run of mergeable pairs (greedy non-overlapping pairs, eds_transforms.cpp:63-66), so a symbol built from
-        // 2^32 leaves - more than the pool can hold - is at most ~33 levels deep plus the rounds in which a product
-        // collapsed and reopened a run; 96 is far beyond what fits in the 32-bit entry pool.  An overflow still raises.
-        u32 stack[96];
-        int sp = 0;
-        stack[sp++] = p.fin_ent[t];
-        while (sp) {
-            const u32 e = stack[--sp];
-            if (p.pool.left[e] == LEAF) {
-                const u64 s0 = p.str_off[p.pool.right[e]], s1 = p.str_off[p.pool.right[e] + 1];
-                for (u64 c = s0; c < s1; c++) *o++ = p.chars[c];
-            } else {
-                if (sp + 2 > 96) { *p.err = 1; break; }
-                stack[sp++] = p.pool.right[e];
-                stack[sp++] = p.pool.left[e];
-            }
-        }
-        if ((fl & 2) && (fl & 4)) *o++ = '}';
-        if (p.linear) {
-            uint8_t* so = p.sout + p.sbytes[t];
-            *so++ = '{';
-            const u64* b = p.pool.bits + (u64)p.fin_ent[t] * p.pool.W;
-            for (u32 w = 0; w < p.pool.W; w++) {
-                u64 v = b[w];
-                while (v) {
-                    u32 id = w * 64 + __builtin_ctzll(v);
-                    v &= v - 1;
-                    u32 nd = ndigits(id ? id : 1);
-                    u32 x = id;
-                    for (int d = (int)nd - 1; d >= 0; d--) { so[d] = (uint8_t)('0' + x % 10); x /= 10; }
-                    so += nd;
-                    *so++ = ',';
+        __syncthreads();
+        while (!ovf) {
+            const u32 n = top;
+            if (n == 0) break;
+            const u32 take = n < 256u ? n : 256u, base = n - take;
+            u32 e = 0, d = 0;
+            if (tid < take) { e = s_ent[base + tid]; d = s_dst[base + tid]; }
+            __syncthreads();                               // every thread has its item and has seen `top`
+            if (tid == 0) top = base;
+            __syncthreads();
+            if (tid < take) {
+                const u32 l = p.pool.left[e], r = p.pool.right[e];
+                if (l == LEAF) {
+                    const u64 s0 = p.str_off[r], s1 = p.str_off[r + 1];
+                    if (s1 - s0 >= FW_LONG_MIN) {
+                        const u32 slot = atomicAdd(&nlong, 1u);
+                        if (slot < FW_LONG) { l_src[slot] = s0; l_dst[slot] = d; l_len[slot] = (u32)(s1 - s0); }
+                        else fin_copy(gout + d, p.chars + s0, s1 - s0);
+                    } else fin_copy(gout + d, p.chars + s0, s1 - s0);
+                } else {
+                    const u32 el = p.pool.elen[l], er = p.pool.elen[r];
+                    const u32 cnt = (el ? 1u : 0u) + (er ? 1u : 0u);
+                    if (cnt) {
+                        u32 slot = atomicAdd(&top, cnt);
+                        if (slot + cnt > FW_STACK) ovf = 1u;
+                        else {
+                            if (er) { s_ent[slot] = r; s_dst[slot] = d + el; slot++; }      // left on top: popped first
+                            if (el) { s_ent[slot] = l; s_dst[slot] = d; }
+                        }
+                    }
                 }
             }
-            so[-1] = '}';
+            __syncthreads();
+            const u32 nl = nlong < FW_LONG ? nlong : FW_LONG;
+            if (nl) {                                       // the long leaves of this round: the whole workgroup copies
+                for (u32 i = 0; i < nl; i++) {
+                    const uint8_t* src = p.chars + l_src[i];
+                    uint8_t* dst = gout + l_dst[i];
+                    const u32 len = l_len[i], full = len & ~15u;
+                    for (u32 c = tid * 16u; c < full; c += 4096u) {
+                        const uint4 v = load16u(src + c);
+                        U128u w{v.x, v.y, v.z, v.w};
+                        __builtin_memcpy(dst + c, &w, 16);
+                    }
+                    if (tid < len - full) dst[full + tid] = src[full + tid];
+                }
+                __syncthreads();
+                if (tid == 0) nlong = 0;
+                __syncthreads();
+            }
         }
+        if (ovf && owner) fin_eds_direct(p, t);            // (rewrites what the stack had placed already: same bytes)
+    }
+}
+
+// "{id,id,...}" of every string's source set (eds.cpp:641-659), a thread per string
+__global__ void k_fin_write_sources(FinParams p, u64 nstr)
+{
+    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < nstr; t += (u64)gridDim.x * blockDim.x) {
+        uint8_t* so = p.sout + p.sbytes[t];
+        *so++ = '{';
+        const u64* b = p.pool.bits + (u64)p.fin_ent[t] * p.pool.W;
+        for (u32 w = 0; w < p.pool.W; w++) {
+            u64 v = b[w];
+            while (v) {
+                u32 id = w * 64 + __builtin_ctzll(v);
+                v &= v - 1;
+                u32 nd = ndigits(id ? id : 1);
+                u32 x = id;
+                for (int d = (int)nd - 1; d >= 0; d--) { so[d] = (uint8_t)('0' + x % 10); x /= 10; }
+                so += nd;
+                *so++ = ',';
+            }
+        }
+        so[-1] = '}';
     }
 }
 
@@ -997,7 +1109,14 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     d_out_.ensure(E + 16);
     if (linear) d_sout_.ensure(Q + 16);
     fp.out = d_out_.as<uint8_t>(); fp.sout = d_sout_.as<uint8_t>();
-    hipLaunchKernelGGL(k_fin_write, dim3(2048), dim3(256), 0, st, fp, nstr);
+    {
+        // strings per workgroup: about 16 KB of text (a power of two, at most one string per thread)
+        const u64 mean = nstr ? std::max<u64>(1, E / nstr) : 1;
+        u32 ns = 256;
+        while (ns > 1 && (u64)ns * mean > 16384) ns >>= 1;
+        if (nstr) hipLaunchKernelGGL(k_fin_write, dim3((unsigned)std::min<u64>((nstr + ns - 1) / ns, 1u << 20)), dim3(256), 0, st, fp, nstr, E, ns);
+        if (linear && nstr) hipLaunchKernelGGL(k_fin_write_sources, dim3(2048), dim3(256), 0, st, fp, nstr);
+    }
     mark("final sizes");
     // malloc'ed, not value-initialised (see HostBytes): the pages are first touched by the copy
     out.take(E + 1);

@@ -1532,26 +1532,49 @@ struct EmitParams {
 
 __global__ void __launch_bounds__(256) k_emit_common(EmitParams p)
 {
+    // A column's byte sits behind three dependent loads (segment ordinal -> segment start -> variant bit / text offset):
+    // a wave takes U words per trip and issues each level of the chain for all of them before the first store.
+    constexpr int U = 4;
     const u32 lane = threadIdx.x & 63;
     const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 w = wave; w < p.nwords; w += nwaves) {
-        const u64 c = w * 64 + lane;
-        if (c >= p.mv.L) continue;
-        const u64 hbits = p.Hseg[w];
-        const u64 below = hbits & ((2ull << lane) - 1ull);
-        const u64 seg = p.segbase[w] + __builtin_popcountll(below) - 1;
-        const u64 a = p.seg_start[seg];
-        if (p.mv.vbit(a)) continue;                          // variant segment: k_emit_variant
-        const u64 e = p.seg_start[seg + 1];
-        const u64 pos = p.eds_off[seg] + 1 + (c - a);
-        p.eds[pos] = (uint8_t)p.mv.ref_byte(c);
-        if (c == a) {
-            p.eds[pos - 1] = '{';
-            uint8_t* s = p.seds + p.seds_off[seg];
-            s[0] = '{'; s[1] = '0'; s[2] = '}';
+    for (u64 w0 = wave; w0 < p.nwords; w0 += nwaves * U) {
+        // (every load below is unconditional - lanes and words past the end read word 0 / the last column - so that the
+        // compiler keeps the U loads of a level together instead of one branch and wait per word)
+        u64 c[U], seg[U], a[U], e[U], pos[U], so[U];
+        u32 ch[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 w = w0 + (u64)u * nwaves;
+            const u64 ws = w < p.nwords ? w : 0;
+            const u64 cr = ws * 64 + lane;
+            on[u] = w < p.nwords && cr < p.mv.L;
+            c[u] = cr < p.mv.L ? cr : p.mv.L - 1;
+            const u64 below = p.Hseg[ws] & ((2ull << (c[u] & 63)) - 1ull);
+            seg[u] = p.segbase[ws] + __builtin_popcountll(below) - 1;
         }
-        if (c == e - 1) p.eds[pos + 1] = '}';
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] = p.seg_start[seg[u]];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            on[u] = on[u] && !p.mv.vbit(a[u]);                // variant segment: k_emit_variant
+            e[u] = p.seg_start[seg[u] + 1];
+            pos[u] = p.eds_off[seg[u]] + 1 + (c[u] - a[u]);
+            ch[u] = p.mv.ref_byte(c[u]);
+            so[u] = p.seds_off[seg[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!on[u]) continue;
+            p.eds[pos[u]] = (uint8_t)ch[u];
+            if (c[u] == a[u]) {
+                p.eds[pos[u] - 1] = '{';
+                uint8_t* s = p.seds + so[u];
+                s[0] = '{'; s[1] = '0'; s[2] = '}';
+            }
+            if (c[u] == e[u] - 1) p.eds[pos[u] + 1] = '}';
+        }
     }
 }
 
@@ -2920,7 +2943,10 @@ MsaPipeline::~MsaPipeline()
 void MsaPipeline::ensure_side_streams()
 {
     if (side_ready_) return;
-    for (auto& x : side_) EDSX_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    // lowest priority: where they run beside the main emitter (EDSX_SIDE=2) they only take what it leaves free
+    int least = 0, greatest = 0;
+    EDSX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (auto& x : side_) EDSX_HIP(hipStreamCreateWithPriority(&x, hipStreamNonBlocking, least));
     for (auto& e : side_ev_) EDSX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     side_ready_ = true;
 }
@@ -3347,16 +3373,19 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
             TIMED(name, st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
                                                dim3(256), 0, st, fp));
         };
+        static int side_env = -1;
+        if (side_env < 0) { const char* e = getenv("EDSX_SIDE"); side_env = e ? atoi(e) : 1; }
+        // (EDSX_SIDE=2, experiment: the side kernels do not wait for the main emitter - the event is taken in front of it -
+        // and fill in on low-priority streams as its persistent workgroups retire)
+        if (side_env == 2) { ensure_side_streams(); EDSX_HIP(hipEventRecord(side_ev_[0], st)); }
         launch_emit(k_emit_fast2, "k_emit_fast");
         // The small emitters behind it are latency-bound (a few hundred workgroups each, dependent loads): they run
         // side by side on streams of their own and join the caller's stream at the end.
-        static int side_env = -1;
-        if (side_env < 0) { const char* e = getenv("EDSX_SIDE"); side_env = e ? atoi(e) : 1; }
         hipStream_t s1 = st, s2 = st;
         if (side_env) {
             ensure_side_streams();
             s1 = side_[0]; s2 = side_[1];
-            EDSX_HIP(hipEventRecord(side_ev_[0], st));
+            if (side_env != 2) EDSX_HIP(hipEventRecord(side_ev_[0], st));
             EDSX_HIP(hipStreamWaitEvent(s1, side_ev_[0], 0));
             EDSX_HIP(hipStreamWaitEvent(s2, side_ev_[0], 0));
         }

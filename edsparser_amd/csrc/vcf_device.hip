@@ -320,20 +320,46 @@ __global__ void k_grp_common(VcfDev d, GrpArrays a)
 
 struct EmitArrays { const u64* eds_off; const u64* seds_off; uint8_t* eds; uint8_t* seds; };
 
-// common text in front of every group: one wave per group, lanes = bytes (the bandwidth part of the output)
+// common text in front of every group (the bandwidth part of the output).  A wave takes 64 consecutive groups: every
+// lane fetches the numbers of one group (length, offsets, position in refc - one round of dependent loads for 64
+// groups instead of one per group) and writes its brackets and "{0}"; then the wave copies the texts one group after the
+// other, 16 bytes per lane (unaligned loads and stores), the ragged end byte by byte.
+__device__ __forceinline__ u64 readlane64(u64 v, int l)
+{
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+    return (u64)lo | ((u64)hi << 32);
+}
 __global__ void __launch_bounds__(256) k_grp_emit_common(VcfDev d, GrpArrays a, EmitArrays e)
 {
     const u32 lane = threadIdx.x & 63;
     const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 g = wave; g < d.ngrp; g += nw) {
-        const u64 clen = a.commonlen[g];
-        if (!clen) continue;
-        uint8_t* eo = e.eds + e.eds_off[g];
-        uint8_t* so = e.seds + e.seds_off[g];
-        const u64 cur = g ? a.cur_after[g - 1] : d.cur0;
-        const u64 c0 = fa_cpos(d, d.seq_start + cur + cur / d.lw);
-        if (lane == 0) { eo[0] = '{'; eo[clen + 1] = '}'; so[0] = '{'; so[1] = '0'; so[2] = '}'; }
-        for (u64 i = lane; i < clen; i += 64) eo[1 + i] = d.refc[c0 + i];
+    for (u64 gb = wave * 64; gb < d.ngrp; gb += nw * 64) {
+        const u64 g = gb + lane;
+        u64 clen = 0, eoff = 0, c0 = 0;
+        if (g < d.ngrp) clen = a.commonlen[g];
+        if (clen) {
+            eoff = e.eds_off[g];
+            uint8_t* eo = e.eds + eoff;
+            uint8_t* so = e.seds + e.seds_off[g];
+            const u64 cur = g ? a.cur_after[g - 1] : d.cur0;
+            c0 = fa_cpos(d, d.seq_start + cur + cur / d.lw);
+            eo[0] = '{'; eo[clen + 1] = '}'; so[0] = '{'; so[1] = '0'; so[2] = '}';
+        }
+        u64 todo = ballot64(clen != 0);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const u64 cl = readlane64(clen, l);
+            uint8_t* dst = e.eds + readlane64(eoff, l) + 1;
+            const uint8_t* src = d.refc + readlane64(c0, l);
+            const u64 full = cl & ~15ull;
+            for (u64 i = (u64)lane * 16; i < full; i += 1024) {
+                const uint4 v = load16u(src + i);
+                U128u w{v.x, v.y, v.z, v.w};
+                __builtin_memcpy(dst + i, &w, 16);
+            }
+            if (lane < (u32)(cl - full)) dst[full + lane] = src[full + lane];
+        }
     }
 }
 
