@@ -175,6 +175,49 @@ def _big_eds(rng, nsym, paths, compact_in, spacing):
     return "".join(eds).encode(), "".join(seds).encode()
 
 
+def _long_leaf_eds(rng, nsym, paths, lens):
+    """variant sites between common strings whose lengths are drawn from `lens` (long leaves of the merge trees)"""
+    eds, seds = [], []
+    for i in range(nsym):
+        if i % 2 == 0:
+            n = rng.choice(lens)
+            eds.append("{" + "".join(rng.choice("ACGT") for _ in range(n)) + "}")
+            seds.append("{0}")
+        else:
+            k = rng.randint(2, 3)
+            alts = ["".join(rng.choice("ACGT") for _ in range(rng.randint(0, 2))) for _ in range(k)]
+            choice = [q if q < k else rng.randrange(k) for q in range(paths)]
+            eds.append("{" + ",".join(alts) + "}")
+            for a in range(k):
+                seds.append("{" + ",".join(str(q + 1) for q in range(paths) if choice[q] == a) + "}")
+    return "".join(eds).encode(), "".join(seds).encode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lens,nsym", [((1, 5, 255, 256, 257, 300), 400), ((3, 4095, 4096, 4113, 9000), 120),
+                                       ((70000, 2, 17), 40), ((1, 2), 6000), ((1, 2), 40000)])
+def test_final_text_long_leaves_and_deep_trees(ctx, lens, nsym):
+    """k_fin_write expands the merge trees level by level: leaves of 256 bytes and more are copied by the whole
+    workgroup (several 4 KB trips for the longest), short ones by the thread that pops them; the strings per
+    workgroup follow the mean string length (1 .. 256).  Context lengths below, between and above the leaf lengths
+    give single-leaf strings, mixed trees and one tree over the whole text; LINEAR and CARTESIAN, both bracket modes."""
+    rng = random.Random(len(lens) * 1000 + nsym)
+    eds, seds = _long_leaf_eds(rng, nsym, 5, lens)
+    for sd in (seds, None):
+        for l in (1, 6, 280, 5000, 100000):
+            if sd is None and l > 1:
+                continue                                     # CARTESIAN products of long chains explode
+            for compact in (True, False):
+                try:
+                    want = o.merge(eds, sd, l, compact)
+                    want = {"out": want[0].decode(), "seds_out": want[1].decode()}
+                except o.OracleError as ex:
+                    want = {"error": str(ex)}
+                got = _run(ctx, eds, sd, l, compact)
+                got.pop("code", None)
+                assert got == want, (lens, nsym, sd is None, l, compact)
+
+
 @pytest.mark.parametrize("compact_in", [False, True])
 def test_parallel_tokenisers_large_inputs(ctx, compact_in):
     """Inputs of 1 MB and more are cut behind '}' and tokenised by several host threads; the result
