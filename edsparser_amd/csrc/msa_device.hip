@@ -2134,7 +2134,7 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
 // instantiation (one column / up to ten DNA columns) hands what it cannot do to the heavy one's list.
 // The descriptor and the first column of the wave's next segment are requested one iteration ahead.
 template <bool HEAVY>
-__global__ void __launch_bounds__(256, HEAVY ? 2 : 4) k_seg_group(FastParams p)
+__global__ void __launch_bounds__(256, HEAVY ? 3 : 4) k_seg_group(FastParams p)
 {
     __shared__ uint8_t strs_all[HEAVY ? 4 * 8192 : 4];
     uint8_t* strs = strs_all + (HEAVY ? (threadIdx.x >> 6) * 8192u : 0u);
