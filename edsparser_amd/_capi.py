@@ -71,7 +71,7 @@ def load_library():
     lib.edsx_last_error.argtypes = [ctypes.c_void_p]
     lib.edsx_last_error.restype = ctypes.c_char_p
     lib.edsx_buf_free.argtypes = [P(_Buf)]
-    lib.edsx_msa_transform.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32,
+    lib.edsx_msa_transform.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
                                        P(_Buf), P(_Buf)]
     lib.edsx_leds_merge.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                     ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, P(_Buf), P(_Buf)]
@@ -150,10 +150,16 @@ class Context:
 
     # ---- host-buffer entry points
     def msa_transform(self, msa, context_len=0):
+        """msa: bytes, or any object with the buffer protocol (a mapped file is handed over in place, not copied)."""
         e, s = _Buf(), _Buf()
-        msa = bytes(msa)
-        self._check(self._lib.edsx_msa_transform(self._h, msa, len(msa), context_len,
-                                                 ctypes.byref(e), ctypes.byref(s)))
+        if isinstance(msa, bytes):
+            ptr, n, keep = msa, len(msa), msa
+        else:
+            import numpy as np
+            keep = np.frombuffer(msa, dtype=np.uint8)
+            ptr, n = ctypes.c_void_p(keep.ctypes.data), int(keep.size)
+        self._check(self._lib.edsx_msa_transform(self._h, ptr, n, context_len, ctypes.byref(e), ctypes.byref(s)))
+        del keep
         return self._take(e), self._take(s)
 
     def leds_merge(self, eds, seds=None, context_len=1, compact=True):

@@ -288,7 +288,6 @@ struct K1Params {
     // fused grouping (context length 0, one-line rows, S <= 1024): the variant runs that lie inside a tile are
     // grouped right here, from the LDS image of the tile's variant columns; only the other columns go to vc
     u32 fuse; u64* Fraw; u32* rec_info; uint8_t* recf; u32 recf_stride, recf_gid;
-    u32 dbg;
 };
 constexpr u32 FUSE_MAXW = 10;      // widest run grouped by the column scan (exact 3-bit-per-column keys in one dword)
 constexpr u32 CLIST = 2048;        // variant columns per tile in fused mode (the LDS image holds at most 64 KB / 32 B columns)
@@ -704,9 +703,7 @@ __device__ __forceinline__ void fused_group_run(const K1Params& p, const uint8_t
     const u32 textlen = 1u + G.k + G.sumlen;             // "{" + strings + separators / "}"
     ok = ok && G.k <= 16u && textlen <= REC_TEXT_MAX;
     const u64 slot = slot_base + idx0;
-    if (p.dbg & 64u) {
-        if (lane == 0 && !ok) p.rec_info[slot] = 0;
-    } else if (ok) {
+    if (ok) {
         uint8_t* rec = p.recf + slot * (u64)p.recf_stride;
         if (lane < nl) {
             if (G.k <= 4u) *reinterpret_cast<u32*>(rec + lane * 4u) = pack_gid2(G.gid, vmask);
@@ -779,15 +776,12 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     const int nb = q < p.Draw ? ((p.Draw - q) < 16 ? (int)(p.Draw - q) : 16) : 0;
     const u32 valid = nb == 16 ? 0xffffu : ((1u << nb) - 1u);
 
-    if ((p.dbg & 1024u) && ((blockIdx.x >> 8) & 1u) && blockIdx.x < 512u) {        // experiment: the two workgroups of a CU out of phase
-        for (int i = 0; i < 3; i++) __builtin_amdgcn_s_sleep(127);
-    }
     // row starts -> LDS (the colbuf area is free until the extraction phase), so the data loads
     // below depend on fast ds_reads only and all RPT of them are in flight together
     // (Full tiles of the lane-rows layout take their 16 consecutive row starts straight from the padded table -
     // eight 16-byte loads that hit L1/L2 - so a wave issues its data loads without waiting for the workgroup.)
     constexpr bool DIRECT_OK = HOLD && LANEROWS;
-    const bool direct = DIRECT_OK && full_tile && !(p.dbg & 8192u);      // workgroup-uniform
+    const bool direct = DIRECT_OK && full_tile;                // workgroup-uniform
     u64* rs = reinterpret_cast<u64*>(colbuf);
     if (!direct) for (u32 r = tid; r < p.S; r += T) rs[r] = p.row_start[r];
     if (tid < 256) { D[tid] = 0; CS[tid] = 0; }
@@ -932,7 +926,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 #undef EDSX_T
         }
         bool fused_tile = false;
-        if constexpr (HOLD && LANEROWS) fused_tile = p.fuse && nv && nv <= cap && nv <= CLIST && !(p.dbg & 128u);   // workgroup-uniform
+        if constexpr (HOLD && LANEROWS) fused_tile = p.fuse && nv && nv <= cap && nv <= CLIST;   // workgroup-uniform
         if (fused_tile) { if constexpr (HOLD && LANEROWS) {
             // ---- all variant columns of the tile -> LDS (column-major, natural row order)
             if (V16) {
@@ -949,7 +943,6 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
             }
             // ---- the runs of variant columns that lie inside the tile and are at most FUSE_MAXW wide are grouped here
             // (registered by the thread that owns their first column); every other variant column goes to vc
-            if (!(p.dbg & 256u))
             for (u32 col = tid; col < cpr * 16u; col += T) {   // one thread per column of the tile
                 const u32 ch = col >> 4, b = col & 15u;
                 const u32 m = D[ch];
@@ -983,15 +976,9 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                 }
             }
             if (!overflow) {
-                if (p.dbg & 2048u) {                           // experiment: copy everything as the unfused path does
-                    const size_t nbytes = (size_t)nv * p.Spad;
-                    uint8_t* g = p.vc + slot_base * (u64)p.Spad;
-                    for (size_t o = (size_t)tid * 16; o < nbytes; o += (size_t)T * 16)
-                        *reinterpret_cast<uint4*>(g + o) = *reinterpret_cast<const uint4*>(colbuf + o);
-                }
                 // ---- the other variant columns: LDS -> vc, one wave per column
                 {
-                    const u32 nst = (p.dbg & 512u) ? 0u : nst_sh, vec = p.Spad / 16u, ln = tid & 63u;
+                    const u32 nst = nst_sh, vec = p.Spad / 16u, ln = tid & 63u;
                     for (u32 c = uniform32(tid >> 6); c < nst; c += T / 64) {
                         const u32 idx = clist[CLIST - 1u - c];
                         const uint8_t* src = colbuf + (size_t)idx * p.Spad;
@@ -1001,7 +988,7 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                     }
                 }
                 // ---- group the runs: one wave per run, lane l = rows 16l .. 16l+15 (msa_transforms.cpp:262-293)
-                const u32 ncand = (p.dbg & 32u) ? 0u : ncand_sh;
+                const u32 ncand = ncand_sh;
                 const u32 lane = tid & 63u, nl = (p.S + 15u) >> 4;
                 const uint4 vmask = fast_valid_mask(lane, p.S);
                 const u32 loff = lane * 16u < p.Spad - 16u ? lane * 16u : p.Spad - 16u;
@@ -2246,7 +2233,7 @@ __device__ __forceinline__ void store16u(uint8_t* p, const uint4& v)   // 16 byt
 template <int BITS, bool HAS5, class Lds, class PreFlush>
 __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, bool v0, bool v1, u32 k, u32 S, u32 lane,
                                         const u32 (&tokc)[16], u32 htok0, u32 htok1, Lds& L, uint8_t* gseds,
-                                        PreFlush pre_flush, u32 dbg = 0)
+                                        PreFlush pre_flush)
 {
     constexpr u32 K = BITS == 2 ? 4u : 16u;        // table rows in use (row K: dummies)
     constexpr int NQ = BITS == 2 ? 1 : 4;          // quartets of strings
@@ -2345,7 +2332,6 @@ __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, 
 #pragma unroll
     for (int g = 0; g < (int)K; g++) L.tab[g * 64 + lane] = L.gt[16 + g] + pre[g];
     // ---- tokens of rows 0..127
-    if (!(dbg & 4u)) {
     if (v0) {
         const u32 a = sbase + L.gt[g0] + ex0;
         lds_put2(a, htok0);
@@ -2362,10 +2348,8 @@ __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, 
         lds_put1<2>(a, htok1 >> 16);
         if (lane >= 35u) lds_put1<3>(a, htok1 >> 24);
     }
-    }
     // ---- tokens of rows 128..
     u32 at[16];
-    if (!(dbg & 2u)) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const bool act = (am & (1u << j)) != 0;
@@ -2382,7 +2366,6 @@ __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, 
             L.stage[five ? at[j] + 4u : (u32)EM_STAGE + 4u * lane] = ',';
         }
     }
-    }
     asm volatile("" ::: "memory");
     // ---- braces (after the tokens: the closing one replaces the last ',')
     if (lane < k) { L.stage[P] = '{'; L.stage[P + sz - 1u] = '}'; }
@@ -2396,7 +2379,6 @@ __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, 
     const u32 cinc = wave_scan_incl(nfull), cs = cinc - nfull;
     const u32 T = (u32)__builtin_amdgcn_readlane((int)cinc, 63);
     if (lane < k) { L.gt[32 + lane] = P + hn - 16u * cs; L.gt[48 + lane] = off + hn - 16u * cs; }
-    if (!(dbg & 1u))
     for (u32 t = lane; t < T; t += 64u) {
         u32 g = 0;
         for (u32 gg = 1; gg < k; gg++) g += t >= (u32)__builtin_amdgcn_readlane((int)cs, (int)gg) ? 1u : 0u;
@@ -2404,7 +2386,6 @@ __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, 
         store16u(gseds + dst, *reinterpret_cast<const uint4*>(L.stage + src));
     }
     const u32 pq = P | (sz << 16), oq = off | (hn << 16);
-    if (!(dbg & 1u))
     for (u32 g = 0; g < k; g++) {
         const u32 a = (u32)__builtin_amdgcn_readlane((int)pq, (int)g), b = (u32)__builtin_amdgcn_readlane((int)oq, (int)g);
         const u32 Pg = a & 0xffffu, szg = a >> 16, og = b & 0xffffu, hg = b >> 16;
@@ -2788,11 +2769,10 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
             asm volatile("" :: "v"(rc_n.x.x), "v"(rc_n.x.y), "v"(rc_n.x.z), "v"(rc_n.x.w), "v"(rc_n.hv), "v"(rc_n.rep),
                                "v"(rc_n.tb), "v"(rc_n.cm), "v"(meta_v), "v"(qoff_v), "v"(eoff_v));
         };
-        if (fast && !(p.dbg & 16u)) {
+        if (fast) {
             // ---- eds: "{" s0 "," s1 ... "}"
             uint8_t* e = p.eds + eoff;
-            if (p.dbg & 8u) {
-            } else if (meta & META_INLINE) {
+            if (meta & META_INLINE) {
                 if (lane < textlen) e[lane] = (uint8_t)rc.tb;
             } else {
                 const u64 cm = uniform64(rc.cm);
@@ -2857,17 +2837,17 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
                                     (eq_byte4((rc.x.z >> 4) & 0x0f0f0f0fu, tt) << 8) | (eq_byte4((rc.x.w >> 4) & 0x0f0f0f0fu, tt) << 12)) & amv;
                     const u32 kt = k - t * 16u < 16u ? k - t * 16u : 16u;
                     run += emit_ids<WIDE ? 4 : 2, HAS5>(xx.x, xx.y, am, G0 & 15u, G1 & 15u, hv0 && (G0 >> 4) == t, hv1 && (G1 >> 4) == t,
-                                             kt, S, lane, tokc, htok0, htok1, L, gseds + run, pre_flush, p.dbg);
+                                             kt, S, lane, tokc, htok0, htok1, L, gseds + run, pre_flush);
                 }
             } else if (WIDE) {
                 const u32 f = lane & 15u, src = lane >> 4;
                 const u32 a0 = lane_read(rc.x.x, src), a1 = lane_read(rc.x.y, src), b0 = lane_read(rc.x.x, src + 4u), b1 = lane_read(rc.x.y, src + 4u);
                 const u32 g0 = (((f & 8u) ? a1 : a0) >> (4u * (f & 7u))) & 15u, g1 = (((f & 8u) ? b1 : b0) >> (4u * (f & 7u))) & 15u;
-                emit_ids<WIDE ? 4 : 2, HAS5>(rc.x.x, rc.x.y, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush, p.dbg);
+                emit_ids<WIDE ? 4 : 2, HAS5>(rc.x.x, rc.x.y, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush);
             } else {
                 const u32 f = lane & 15u, src = lane >> 4;
                 const u32 g0 = (lane_read(rc.x.x, src) >> (2u * f)) & 3u, g1 = (lane_read(rc.x.x, src + 4u) >> (2u * f)) & 3u;
-                emit_ids<WIDE ? 2 : 2, HAS5>(rc.x.x, 0u, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush, p.dbg);
+                emit_ids<WIDE ? 2 : 2, HAS5>(rc.x.x, 0u, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush);
             }
         } else pre_flush();
     }
@@ -3065,23 +3045,16 @@ void MsaPipeline::plan_body(hipStream_t st)
     // ---- K1 geometry.  A workgroup of T threads keeps RPT 16-byte chunks per thread in registers:
     // rows per pass = T / CPR, tile width W = 16 * CPR columns.  Two workgroups per CU let one
     // tile's extraction phase overlap the other's load phase.
-    //   cfg 0: T=1024 RPT=16  (1 workgroup/CU, widest tile)
-    //   cfg 1: T=512  RPT=16  (2 workgroups/CU)
-    //   cfg 2: T=1024 RPT=8   (2 workgroups/CU, <= 64 VGPRs)
-    static int cfg_env = -1;
-    if (cfg_env < 0) { const char* e = getenv("EDSX_K1"); cfg_env = e ? atoi(e) : 1; if (cfg_env < 0 || cfg_env > 2) cfg_env = 1; }
-    int cfg = cfg_env;
-    const int T = cfg == 1 ? 512 : 1024, RPT = cfg == 2 ? 8 : 16;
+    // T = 512, RPT = 16: two workgroups per CU (1024 threads x 16 and 1024 x 8 were measured in round 1: slower).
+    const int T = 512, RPT = 16;
     u32 cpr_log2 = 8;
     while (cpr_log2 > 2 && (u64)RPT * (T >> cpr_log2) < S) cpr_log2--;
     const bool hold = (u64)RPT * (T >> cpr_log2) >= S;
     const u64 W = 16ull << cpr_log2;
     const u64 ntiles = (Draw + W - 1) / W;
-    static int cb_env = -1;
-    if (cb_env < 0) { const char* e = getenv("EDSX_K1_LDS"); cb_env = e ? atoi(e) : 0; }
     // 40 KB of column image (39 columns of 1000 rows; denser tiles take the batched path) leave room for a third
     // workgroup per CU to start while the two resident ones finish their grouping tails (-1.7 % on the scan)
-    const size_t colbuf_bytes = cb_env ? (size_t)cb_env * 1024 : cfg == 0 ? 96 * 1024 : ((size_t)S * 8 <= 40 * 1024 ? 40 * 1024 : 64 * 1024);
+    const size_t colbuf_bytes = (size_t)S * 8 <= 40 * 1024 ? 40 * 1024 : 64 * 1024;
     if (ntiles > 0x7fffffffull) throw FormatError("MSA too large for one launch");
     if (colbuf_bytes < (size_t)S * 8) throw LimitError(status_message(ST_TOO_MANY_ROWS));
 
@@ -3093,10 +3066,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     if (kp.cap_cols == 0) throw LimitError(status_message(ST_TOO_MANY_ROWS));
     const bool lane_rows = hold && RPT == 16;             // thread rows = 16 consecutive rows = 16 consecutive vc bytes
     // fused grouping: context length 0 (segments = runs), one-line rows (raw position = column), wave-per-segment code
-    static int fuse_env = -1;
-    if (fuse_env < 0) { const char* e = getenv("EDSX_FUSE"); fuse_env = e ? atoi(e) : 1; }
-    fuse_ = fuse_env && l == 0 && lw == 0 && S <= 1024 && lane_rows && cfg != 2;
-    { const char* e = getenv("EDSX_DBG"); kp.dbg = e ? (u32)atoi(e) : 0u; }
+    fuse_ = l == 0 && lw == 0 && S <= 1024 && lane_rows;
     kp.fuse = fuse_ ? 1u : 0u; kp.Fraw = nullptr; kp.rec_info = nullptr; kp.recf = nullptr; kp.recf_stride = 0; kp.recf_gid = 0;
     if (fuse_) {
         recf_gid_ = (8u * (((u32)S + 15u) / 16u) + 15u) & ~15u;
@@ -3108,19 +3078,10 @@ void MsaPipeline::plan_body(hipStream_t st)
         kp.recf_stride = recf_stride_; kp.recf_gid = recf_gid_;
     }
     launch_timer_begin("k_scan_extract", st);
-    if (cfg == 1) {
-        if (lane_rows && fuse_ && S <= 64) launch_k1<512, 16, true, true, 4, true>(kp, colbuf_bytes, st);   // one row per lane in the fused grouping
-        else if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
-        else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
-        else launch_k1<512, 16, false, false, 4>(kp, colbuf_bytes, st);
-    } else if (cfg == 2) {
-        if (hold) launch_k1<1024, 8, true, false, 8>(kp, colbuf_bytes, st);
-        else launch_k1<1024, 8, false, false, 8>(kp, colbuf_bytes, st);
-    } else {
-        if (lane_rows) launch_k1<1024, 16, true, true, 4>(kp, colbuf_bytes, st);
-        else if (hold) launch_k1<1024, 16, true, false, 4>(kp, colbuf_bytes, st);
-        else launch_k1<1024, 16, false, false, 4>(kp, colbuf_bytes, st);
-    }
+    if (lane_rows && fuse_ && S <= 64) launch_k1<512, 16, true, true, 4, true>(kp, colbuf_bytes, st);   // one row per lane in the fused grouping
+    else if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
+    else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
+    else launch_k1<512, 16, false, false, 4>(kp, colbuf_bytes, st);
     launch_timer_end(st);
 
     const u64* V = lw ? v_.as<u64>() : vraw_.as<u64>();
@@ -3167,19 +3128,16 @@ void MsaPipeline::plan_body(hipStream_t st)
     {                                                     // as many columns of a segment as fit beside that (<= STAGE_COLS)
         const size_t budget = (size_t)150 * 1024;
         const size_t maps = 2 * (size_t)STAGE_WMAX + 16;     // column map + reference bytes of the common columns
-        static int two_env = -1;
-        if (two_env < 0) { const char* e = getenv("EDSX_GEN2"); two_env = e ? atoi(e) : 1; }
-        static int mincol_env = -1;
-        if (mincol_env < 0) { const char* e = getenv("EDSX_GEN_MINCOLS"); mincol_env = e ? atoi(e) : 24; }
+        constexpr size_t GEN_MINCOLS = 24;
         // two (or three) workgroups per CU if 24 columns and more still fit - 8 for more than 1024 rows, which have no other
         // path (wider segments keep their variant columns + a column map)
         const size_t nblk = (S + 63) / 64, S2 = (S + 1) & ~(size_t)1;
         const size_t walk_cols = (nblk * 384 + S2 * 3 + nblk + 16 + Spad + 7) / ((size_t)Spad + 8);     // the emitter's tables for the .seds walk live there too
-        const size_t mincols = S > 1024 ? std::max<size_t>(8, walk_cols) : (size_t)mincol_env;
+        const size_t mincols = S > 1024 ? std::max<size_t>(8, walk_cols) : GEN_MINCOLS;
         size_t use = budget;
-        for (int n = two_env > 1 ? two_env : 2; n >= 2 && two_env; n--) {
-            const size_t part = (size_t)(150 / n - 1) * 1024;
-            if (seg_lds_ + maps + mincols * ((size_t)Spad + 8) <= part) { use = part; break; }
+        {
+            const size_t part = (size_t)(150 / 2 - 1) * 1024;
+            if (seg_lds_ + maps + mincols * ((size_t)Spad + 8) <= part) use = part;
         }
         if (seg_lds_ + maps + 4 * ((size_t)Spad + 8) <= use) {
             stage_cols_ = (u32)std::min<size_t>(STAGE_COLS, (use - seg_lds_ - maps) / ((size_t)Spad + 8));
@@ -3368,24 +3326,19 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
         // measured: the persistent main emitter fills every CU, the side kernels only slow it down - 41.0 vs 39.7 ms.)
         FastParams fp = fp_;
         fp.eds = d_eds; fp.seds = d_seds;
-        { const char* e = getenv("EDSX_DBG"); fp.dbg = e ? (u32)atoi(e) : 0u; }
         auto launch_emit = [&](auto kern, const char* name) {
             TIMED(name, st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
                                                dim3(256), 0, st, fp));
         };
-        static int side_env = -1;
-        if (side_env < 0) { const char* e = getenv("EDSX_SIDE"); side_env = e ? atoi(e) : 1; }
-        // (EDSX_SIDE=2, experiment: the side kernels do not wait for the main emitter - the event is taken in front of it -
-        // and fill in on low-priority streams as its persistent workgroups retire)
-        if (side_env == 2) { ensure_side_streams(); EDSX_HIP(hipEventRecord(side_ev_[0], st)); }
+        // (side kernels that do not wait for the main emitter, on low-priority streams: measured in round 2, inside the noise)
         launch_emit(k_emit_fast2, "k_emit_fast");
         // The small emitters behind it are latency-bound (a few hundred workgroups each, dependent loads): they run
         // side by side on streams of their own and join the caller's stream at the end.
         hipStream_t s1 = st, s2 = st;
-        if (side_env) {
+        {
             ensure_side_streams();
             s1 = side_[0]; s2 = side_[1];
-            if (side_env != 2) EDSX_HIP(hipEventRecord(side_ev_[0], st));
+            EDSX_HIP(hipEventRecord(side_ev_[0], st));
             EDSX_HIP(hipStreamWaitEvent(s1, side_ev_[0], 0));
             EDSX_HIP(hipStreamWaitEvent(s2, side_ev_[0], 0));
         }
@@ -3403,7 +3356,7 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
         TIMED("k_emit_variant_slow", s2, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
         ep.list = fp_.slow_list2; ep.list_n = fp_.slow_count2; ep.gcache = gcache_.as<uint8_t>() + gc_region_;
         TIMED("k_emit_variant_slow2", s2, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
-        if (side_env) {
+        {
             EDSX_HIP(hipEventRecord(side_ev_[1], s1));
             EDSX_HIP(hipEventRecord(side_ev_[2], s2));
             EDSX_HIP(hipStreamWaitEvent(st, side_ev_[1], 0));

@@ -133,7 +133,6 @@ struct FastParams {
     uint8_t* rec; u32 rec_stride, rec_gid;  // grouping records (count -> emit): stride, bytes of the group-id area
     const u64* Fraw; const u32* rec_info;   // column scan's own groupings: first-column bitmap, k | textlen << 8 | ok << 31 per slot
     const uint8_t* recf; u32 recf_stride, recf_gid;   // ... and their records (indexed by slot)
-    u32 dbg = 0;                            // EDSX_DBG: timing experiments (skips phases; output is then wrong)
 };
 
 class MsaPipeline {

@@ -131,9 +131,8 @@ void EDS::rebuild_metadata()
             metadata_.string_lengths.push_back(static_cast<Length>(s.size()));
             N_ += s.size();
             if (s.empty()) metadata_.num_empty_strings++;
-            if (deg) metadata_.total_change_size += s.size();
         }
-        if (deg) metadata_.num_degenerate_symbols++;
+        if (deg) { metadata_.num_degenerate_symbols++; metadata_.total_change_size += set.size() - 1; }   // eds.cpp:397-399
         else {
             const Length len = static_cast<Length>(set[0].size());
             metadata_.num_common_chars += len;
@@ -157,6 +156,63 @@ void EDS::rebuild_metadata()
         }
         metadata_.num_paths = all.size();
         metadata_.avg_paths_per_string = sources_.empty() ? 0.0 : static_cast<double>(total) / sources_.size();
+    }
+}
+
+EDS::Statistics EDS::get_statistics() const
+{
+    const Metadata& md = metadata_;
+    return Statistics{md.min_context_length, md.max_context_length, md.avg_context_length, md.num_degenerate_symbols,
+                      md.num_common_chars, md.total_change_size, md.num_empty_strings, md.num_paths,
+                      md.max_paths_per_string, md.avg_paths_per_string};
+}
+
+// The summary block of the reference (eds.cpp:528-557): titled groups of "label value" lines, labels padded to 32 columns.
+void EDS::print_statistics(std::ostream& os) const
+{
+    const Statistics st = get_statistics();
+    struct Line { const char* label; std::string value; };
+    struct Group { const char* title; std::vector<Line> lines; };
+    auto num = [](auto v) { std::ostringstream o; o << v; return o.str(); };
+    const Group groups[] = {
+        {"Structure", {{"Number of sets (n):", num(n_)}, {"Total characters (N):", num(N_)}, {"Total strings (m):", num(m_)},
+                       {"Degenerate symbols:", num(st.num_degenerate_symbols)},
+                       {"Regular symbols:", num(n_ - st.num_degenerate_symbols)}}},
+        {"Context Lengths", {{"Minimum:", num(st.min_context_length)}, {"Maximum:", num(st.max_context_length)},
+                             {"Average:", num(st.avg_context_length)}}},
+        {"Variations", {{"Total change size:", num(st.total_change_size)}, {"Common characters:", num(st.num_common_chars)},
+                        {"Empty strings:", num(st.num_empty_strings)}}},
+    };
+    const std::string rule(40, '=');
+    os << rule << "\nEDS Statistics\n" << rule << "\n";
+    for (const Group& g : groups) {
+        os << g.title << ":\n";
+        for (const Line& ln : g.lines) {
+            std::string label = std::string("  ") + ln.label;
+            label.resize(32, ' ');
+            os << label << ln.value << "\n";
+        }
+        os << "\n";
+    }
+    if (has_sources_) os << "Sources: Loaded (" << sources_.size() << " strings with source info)\n";
+    else os << "Sources: Not loaded\n";
+    os << rule << "\n";
+}
+
+void EDS::print(std::ostream& os) const
+{
+    if (is_empty_) { os << "(empty EDS)\n"; return; }
+    os << "EDS with " << n_ << " sets, " << m_ << " total strings:\n";
+    for (size_t i = 0; i < sets_.size(); ++i) {
+        os << "Set " << i << ": {";
+        const char* sep = "";
+        for (const std::string& str : sets_[i]) {
+            os << sep;
+            if (str.empty()) os << "\xce\xb5";                 // epsilon for the empty string
+            else os << '"' << str << '"';
+            sep = ", ";
+        }
+        os << (metadata_.is_degenerate[i] ? "} [degenerate]\n" : "}\n");
     }
 }
 

@@ -124,6 +124,14 @@ def piece_bounds(edges, action):
     return e_lo, e_hi, s_lo, s_hi
 
 
+class RemoteRankError(RuntimeError):
+    """Another rank's step failed; the message is that rank's own error text."""
+
+    def __init__(self, rank, text):
+        super().__init__(text)
+        self.rank, self.message = rank, text
+
+
 class TensorComm:
     """The exchanges of the partitions as tensor collectives (no pickled objects): all_gather_into_tensor of int64
     vectors of a fixed length, and of uint8 payloads padded to the largest contribution (their sizes travel first).
@@ -159,6 +167,21 @@ class TensorComm:
             buf[:len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
         g = self._gather(buf.to(self._dev()))
         return [g[r, :sizes[r]].numpy().tobytes() for r in range(self.world)]
+
+    def raise_if_any_failed(self, err):
+        """Collective: every rank passes its own exception (or None).  When any rank failed, the failing ranks' error
+        texts travel as one payload exchange; a failing rank re-raises its own exception, every other rank raises
+        RemoteRankError with the text of the lowest failing rank - so no rank is left waiting in a later collective
+        and whichever rank prints has the reference-worded message."""
+        flags = [v[0] for v in self.ints([0 if err is None else 1])]
+        if not any(flags):
+            return
+        text = "" if err is None else str(getattr(err, "message", None) or err)
+        texts = self.payloads(text.encode("utf-8", "replace"))
+        if err is not None:
+            raise err
+        first = flags.index(1)
+        raise RemoteRankError(first, texts[first].decode("utf-8", "replace"))
 
 
 EDGE_FIELDS = ("n_segments", "cols", "eds_bytes", "seds_bytes", "first_is_variant", "first_cols", "first_eds_bytes",
@@ -356,13 +379,20 @@ class MsaSharder:
     def __init__(self, rank, world, dist, slab_fn, mini_fn, whole_fn, device=None):
         self.rank, self.world, self.dist = rank, world, dist
         self.slab_fn, self.mini_fn, self.whole_fn, self.device = slab_fn, mini_fn, whole_fn, device
+        self.comm = TensorComm(dist, world, device)
 
     def run(self, msa, context_len=0):
         rank, world = self.rank, self.world
         layout = msa_layout(msa) if context_len == 0 else None
         if layout is None or layout[3] < 2 * world or world == 1:
             # not partitioned (l-EDS boundaries look across runs, msa_transforms.cpp:133-190; odd files): rank 0 alone
-            eds, seds = self.whole_fn(bytes(msa), context_len) if rank == 0 else (b"", b"")
+            eds, seds, err = b"", b"", None
+            if rank == 0:
+                try:
+                    eds, seds = self.whole_fn(msa, context_len)
+                except Exception as ex:                            # noqa: BLE001 — raised on every rank below
+                    err = ex
+            self.comm.raise_if_any_failed(err)
             import torch
             dev = self.device or ("cuda" if self.dist.get_backend() == "nccl" else "cpu")
             t = torch.tensor([len(eds), len(seds)], dtype=torch.int64, device=dev)
@@ -372,7 +402,12 @@ class MsaSharder:
                     "partitioned": False}
         starts, _draw, _lw, L = layout
         c0, c1 = L * rank // world, L * (rank + 1) // world
-        eds, seds, edges, get_columns = self.slab_fn(msa_slab_image(msa, layout, c0, c1), len(starts), c1 - c0)
+        eds, seds, edges, get_columns, err = b"", b"", None, None, None
+        try:
+            eds, seds, edges, get_columns = self.slab_fn(msa_slab_image(msa, layout, c0, c1), len(starts), c1 - c0)
+        except Exception as ex:                                    # noqa: BLE001 — raised on every rank below
+            err = ex
+        self.comm.raise_if_any_failed(err)                         # before the stitch: no rank waits in its collectives
         st = SlabStitcher(rank, world, len(starts), self.dist, self.mini_fn, lambda: edges, get_columns, device=self.device)
         res = st.stitch()
         e, s = stitched_piece(eds, seds, res)
@@ -595,11 +630,8 @@ class VcfSharder:
                 groups = st["variant_groups"]
             except Exception as ex:                                # noqa: BLE001 — re-raised on every rank below
                 err = ex
-        sizes = self.comm.ints([len(eds), len(seds), groups, 0 if err is None else 1])
-        if any(s[3] for s in sizes):
-            if err is not None:
-                raise err                                          # the rank that failed words the error
-            raise RuntimeError("VCF range transform failed on rank %d" % [s[3] for s in sizes].index(1))
+        self.comm.raise_if_any_failed(err)                         # the failing rank's own wording reaches every rank
+        sizes = self.comm.ints([len(eds), len(seds), groups])
         stats = {k: sum(g[2][k] for g in gathered) for k in
                  ("total_variants", "processed_variants", "skipped_malformed", "skipped_unsupported_sv")}
         stats["variant_groups"] = sum(s[2] for s in sizes)
@@ -754,11 +786,8 @@ class MergeSharder:
                 out, sout = self.whole_fn(eds, seds, l, compact)
             except Exception as ex:  # noqa: BLE001 — raised on every rank below
                 err = ex
-        sizes = self.comm.ints([len(out), len(sout), 0 if err is None else 1])
-        if sizes[0][2]:
-            if err is not None:
-                raise err                                          # rank 0 words the reference's error
-            raise RuntimeError("merge failed on rank 0")
+        self.comm.raise_if_any_failed(err)                         # rank 0 words the reference's error, on every rank
+        sizes = self.comm.ints([len(out), len(sout)])
         self.last = {"leds": out, "seds": sout, "partitioned": False, "why": why, "ranges": 1,
                      "leds_offset": 0 if self.rank == 0 else sizes[0][0], "seds_offset": 0 if self.rank == 0 else sizes[0][1],
                      "leds_total": sizes[0][0], "seds_total": sizes[0][1]}

@@ -1,7 +1,8 @@
 // edsparser/formats/eds.hpp — in-memory EDS container (hot subset of the reference's class,
 // src/cpp/lib/formats/eds.hpp:26-169): parse / save / sources / pairwise merge / metadata.
-// The query-side utilities of the reference (pattern sampling, extract, check_position,
-// METADATA_ONLY streaming) are outside the transform hot path and are not provided.
+// Statistics / get_statistics / print_statistics / print as eds.hpp:107-129.  The query-side utilities of the
+// reference (pattern sampling, extract, check_position, METADATA_ONLY streaming) are outside the transform
+// hot path and are not provided.
 #ifndef EDSPARSER_EDS_HPP
 #define EDSPARSER_EDS_HPP
 
@@ -59,6 +60,23 @@ public:
         double avg_paths_per_string = 0.0;
     };
     const Metadata& get_metadata() const { return metadata_; }
+
+    // The statistics portion of the metadata (reference: eds.hpp:107-123).
+    struct Statistics {
+        Length min_context_length;
+        Length max_context_length;
+        double avg_context_length;
+        size_t num_degenerate_symbols;
+        size_t num_common_chars;
+        size_t total_change_size;
+        size_t num_empty_strings;
+        size_t num_paths;
+        size_t max_paths_per_string;
+        double avg_paths_per_string;
+    };
+    Statistics get_statistics() const;
+    void print_statistics(std::ostream& os = std::cout) const;     // the reference's summary block (eds.cpp:528-557)
+    void print(std::ostream& os = std::cout) const;                // one line per set (eds.cpp:559-598)
 
     void save(std::ostream& os, OutputFormat format = OutputFormat::FULL) const;
     void save(const std::filesystem::path& path, OutputFormat format = OutputFormat::FULL) const;

@@ -112,4 +112,18 @@ extern "C" int ref_eds_stats(const uint8_t* eds, size_t eds_n, const uint8_t* se
     } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return 2; }
 }
 
+// which = 0: EDS::print_statistics, 1: EDS::print (eds.cpp:528-598) of the real reference, as text
+extern "C" int ref_eds_print(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, int which,
+                             char** out, size_t* out_n, char* err, size_t errcap)
+{
+    try {
+        const std::string es(reinterpret_cast<const char*>(eds), eds_n);
+        edsparser::EDS e = seds ? edsparser::EDS(es, std::string(reinterpret_cast<const char*>(seds), seds_n)) : edsparser::EDS(es);
+        std::ostringstream os;
+        if (which == 0) e.print_statistics(os); else e.print(os);
+        *out = dup_out(os.str(), out_n);
+        return 0;
+    } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return 2; }
+}
+
 extern "C" void ref_free(void* p) { free(p); }

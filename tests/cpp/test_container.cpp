@@ -5,6 +5,7 @@
 #include "edsparser/transforms/eds_transforms.hpp"
 
 #include <cstdio>
+#include <fstream>
 #include <sstream>
 #include <stdexcept>
 
@@ -19,8 +20,39 @@ template <class F> static std::string what_of(F&& f)
     return "";
 }
 
-int main()
+// print_statistics / print against the reference's own text (tests/golden/print_cases.txt, written by
+// tests/golden/make_golden3.py from the compiled reference; format: see there)
+static void check_print_cases(const char* path)
 {
+    std::ifstream f(path, std::ios::binary);
+    CHECK(f.good());
+    std::string eds, seds, line;
+    int ncases = 0;
+    auto block = [&]() {
+        std::getline(f, line);
+        std::string b((size_t)std::stoul(line), '\0');
+        f.read(&b[0], (std::streamsize)b.size());
+        f.get();                                   // the newline behind the block
+        return b;
+    };
+    while (std::getline(f, eds) && std::getline(f, seds)) {
+        const std::string want_stats = block(), want_print = block();
+        EDS e = seds == "-" ? EDS(eds) : EDS(eds, seds);
+        std::ostringstream a, b;
+        e.print_statistics(a);
+        e.print(b);
+        CHECK(a.str() == want_stats);
+        CHECK(b.str() == want_print);
+        const EDS::Statistics st = e.get_statistics();
+        CHECK(st.min_context_length == e.get_metadata().min_context_length && st.num_paths == e.get_metadata().num_paths);
+        ncases++;
+    }
+    CHECK(ncases >= 6);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc > 1) check_print_cases(argv[1]);
     {   // cartesian merges
         EDS eds("{G,C}{T}");
         EDS m = eds.merge_adjacent(0, 1);

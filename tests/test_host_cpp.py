@@ -27,7 +27,8 @@ def _compile(src, out):
 
 def test_container_cpu():
     exe = _compile(os.path.join(ROOT, "tests", "cpp", "test_container.cpp"), os.path.join(BUILD, "test_container"))
-    r = subprocess.run([exe], capture_output=True, text=True)
+    # + EDS::print_statistics / print against the reference's own text (tests/golden/make_golden3.py)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "print_cases.txt")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
 
 

@@ -123,3 +123,54 @@ def test_msa_layout_and_slab_images():
         assert mg.msa_slab_image(msa, lay, c0, c1) == b"".join(b">r\n" + r[c0:c1] + b"\n" for r in rows), (it, lw, c0, c1)
     assert mg.msa_layout(b"") is None and mg.msa_layout(b"ACGT\n") is None and mg.msa_layout(b">a\nACGT\n") is None
     assert mg.msa_layout(b">a\nACGT\n>b\nAC\n") is None            # ragged rows: left to the unpartitioned transform
+
+
+# ---- a failure on one rank reaches every rank with its own wording (no rank is left in a collective) ----------
+def _failing_worker(rank, world, port, what, q):
+    import torch.distributed as dist
+    from edsparser_amd import multigpu as mg
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    text, kind = "", ""
+    try:
+        if what == "vcf":
+            def range_fn(lines, fasta, cur0, nxt):
+                if rank == 1:
+                    raise ValueError("Invalid FASTA: rank one's wording")
+                return o.vcf_range(lines, fasta, cur0, nxt)
+            rng = random.Random(3)
+            ref = "".join(rng.choice("ACGT") for _ in range(2000))
+            vcf, fasta = _vcf(ref, _random_records(rng, ref, 200, 4), 4)
+            mg.VcfSharder(rank, world, dist, o.vcf_index, o.vcf_sort_order, range_fn).run(vcf, fasta)
+        else:
+            from msa_cases import random_msa
+            inner = _oracle_msa_sharder(mg, rank, world, dist)
+
+            def slab_fn(image, n_rows, ncols):
+                if rank == 1:
+                    raise RuntimeError("Invalid MSA: slab one's wording")
+                return inner.slab_fn(image, n_rows, ncols)
+            msa = random_msa(random.Random(5), S=4, L=400)
+            mg.MsaSharder(rank, world, dist, slab_fn, inner.mini_fn, inner.whole_fn).run(msa, 0)
+    except Exception as ex:  # noqa: BLE001
+        text, kind = str(ex), type(ex).__name__
+    finally:
+        dist.destroy_process_group()
+    q.put((rank, kind, text))
+
+
+@pytest.mark.parametrize("what", ["vcf", "msa"])
+def test_failure_on_rank_one_is_worded_on_every_rank(what):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, what, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (k, t)) for r, k, t in (q.get(timeout=120) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = "Invalid FASTA: rank one's wording" if what == "vcf" else "Invalid MSA: slab one's wording"
+    assert got[1][1] == want and got[1][0] in ("ValueError", "RuntimeError")          # the failing rank: its own exception
+    assert got[0] == ("RemoteRankError", want)                                          # its peer: the same text, no hang
