@@ -5,4 +5,4 @@ edsparser_amd/build.py) used by the tests and bench.py.  The product is the HIP 
 C++ `edsparser::` host shims in edsparser_amd/host/.  There is no CPU fallback: importing works
 anywhere, but creating a Context without a gfx950 GPU raises.
 """
-from ._capi import Context, EdsxError, lib_path, load_library, synth_size  # noqa: F401
+from ._capi import Context, EdsxError, MultiGpu, lib_path, load_library, synth_size  # noqa: F401

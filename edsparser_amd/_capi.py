@@ -108,8 +108,61 @@ def load_library():
     lib.edsx_msa_synth_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
                                           ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double, ctypes.c_uint64,
                                           ctypes.c_void_p, P(ctypes.c_size_t)]
+    lib.edsx_multi_create.argtypes = [P(ctypes.c_int), ctypes.c_int, ctypes.c_int, P(ctypes.c_void_p)]
+    lib.edsx_multi_destroy.argtypes = [ctypes.c_void_p]
+    lib.edsx_multi_last_error.argtypes = [ctypes.c_void_p]
+    lib.edsx_multi_last_error.restype = ctypes.c_char_p
+    lib.edsx_msa_transform_multi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, P(_Buf), P(_Buf)]
+    lib.edsx_multi_last_partition.argtypes = [ctypes.c_void_p, P(ctypes.c_int), P(ctypes.c_int)]
     _LIB = lib
     return lib
+
+
+class MultiGpu:
+    """edsx_multi: MSA -> EDS over several GPUs from one process (C++ rank threads, RCCL or in-process exchange)."""
+
+    def __init__(self, devices, use_rccl=True):
+        self._lib = load_library()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = self._lib.edsx_multi_create(arr, len(devices), 1 if use_rccl else 0, ctypes.byref(h))
+        if rc != 0:
+            raise EdsxError(rc, "edsx_multi_create failed for devices %r (rccl=%r)" % (list(devices), use_rccl))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.edsx_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def msa_transform(self, msa, context_len=0):
+        e, s = _Buf(), _Buf()
+        if isinstance(msa, bytes):
+            ptr, n, keep = msa, len(msa), msa
+        else:
+            import numpy as np
+            keep = np.frombuffer(msa, dtype=np.uint8)
+            ptr, n = ctypes.c_void_p(keep.ctypes.data), int(keep.size)
+        rc = self._lib.edsx_msa_transform_multi(self._h, ptr, n, context_len, ctypes.byref(e), ctypes.byref(s))
+        del keep
+        if rc != 0:
+            raise EdsxError(rc, self._lib.edsx_multi_last_error(self._h).decode(errors="replace"))
+        out = []
+        for b in (e, s):
+            out.append(ctypes.string_at(b.data, b.size) if b.size else b"")
+            self._lib.edsx_buf_free(ctypes.byref(b))
+        return out[0], out[1]
+
+    def last_partition(self):
+        p, c = ctypes.c_int(), ctypes.c_int()
+        self._lib.edsx_multi_last_partition(self._h, ctypes.byref(p), ctypes.byref(c))
+        return bool(p.value), int(c.value)
 
 
 def synth_size(n_rows, n_cols):

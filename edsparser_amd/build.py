@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libedsx.so")
-SOURCES = ["msa_device.hip", "merge_device.hip", "vcf_device.hip", "synth.hip", "genrandom.hip", "capi.hip"]
+SOURCES = ["msa_device.hip", "merge_device.hip", "vcf_device.hip", "synth.hip", "genrandom.hip", "multi_gpu.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -38,7 +38,7 @@ def _compile(src, obj, extra, verbose):
 
 def _link(objs, lib, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]   # RCCL: the multi-GPU boundary stitch
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -4,11 +4,13 @@
 #include "genrandom.hpp"
 #include "merge_device.hpp"
 #include "msa_device.hpp"
+#include "multi_gpu.hpp"
 #include "synth.hpp"
 #include "vcf_device.hpp"
 
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -144,6 +146,56 @@ int edsx_msa_locate_segment(edsx_ctx* ctx, uint64_t col, uint64_t* seg, uint64_t
         const MsaPipeline::SegLoc r = ctx->msa.locate(col, nullptr);
         *seg = r.seg; *seg_col = r.col; *eds_off = r.eds_off; *seds_off = r.seds_off;
     });
+}
+
+struct edsx_multi_impl { std::unique_ptr<MultiMsa> m; std::string err; };
+
+int edsx_multi_create(const int* device_ids, int n, int use_rccl, edsx_multi** out)
+{
+    if (!out) return EDSX_ERR_INVALID_PARAMETER;
+    *out = nullptr;
+    if (!device_ids || n <= 0) return EDSX_ERR_INVALID_PARAMETER;
+    edsx_multi_impl* mi = new (std::nothrow) edsx_multi_impl();
+    if (!mi) return EDSX_ERR_BUILD_FAILED;
+    try {
+        mi->m.reset(new MultiMsa(std::vector<int>(device_ids, device_ids + n), use_rccl != 0));
+    } catch (const ParamError&) { delete mi; return EDSX_ERR_INVALID_PARAMETER;
+    } catch (const std::exception&) { delete mi; return EDSX_ERR_BUILD_FAILED; }
+    *out = reinterpret_cast<edsx_multi*>(mi);
+    return EDSX_OK;
+}
+void edsx_multi_destroy(edsx_multi* m) { delete reinterpret_cast<edsx_multi_impl*>(m); }
+const char* edsx_multi_last_error(const edsx_multi* m)
+{
+    return m ? reinterpret_cast<const edsx_multi_impl*>(m)->err.c_str() : "null handle";
+}
+int edsx_msa_transform_multi(edsx_multi* m, const uint8_t* msa, size_t msa_size, uint32_t context_len, edsx_buf* eds, edsx_buf* seds)
+{
+    if (eds) { eds->data = nullptr; eds->size = 0; }
+    if (seds) { seds->data = nullptr; seds->size = 0; }
+    edsx_multi_impl* mi = reinterpret_cast<edsx_multi_impl*>(m);
+    if (!mi || !msa || !eds || !seds) return EDSX_ERR_INVALID_PARAMETER;
+    try {
+        mi->err.clear();
+        HostBytes e, s;
+        mi->m->transform(msa, msa_size, context_len, e, s);
+        eds->size = e.size; eds->data = e.release();
+        seds->size = s.size; seds->data = s.release();
+        return EDSX_OK;
+    } catch (const FormatError& ex) { mi->err = ex.what(); return EDSX_ERR_INVALID_FORMAT;
+    } catch (const ParamError& ex) { mi->err = ex.what(); return EDSX_ERR_INVALID_PARAMETER;
+    } catch (const LimitError& ex) { mi->err = ex.what(); return EDSX_ERR_BUILD_FAILED;
+    } catch (const DeviceError& ex) { mi->err = ex.what(); return EDSX_ERR_BUILD_FAILED;
+    } catch (const std::bad_alloc&) { mi->err = "out of host memory"; return EDSX_ERR_BUILD_FAILED;
+    } catch (const std::exception& ex) { mi->err = ex.what(); return EDSX_ERR_UNKNOWN; }
+}
+int edsx_multi_last_partition(const edsx_multi* m, int* partitioned, int* chains)
+{
+    const edsx_multi_impl* mi = reinterpret_cast<const edsx_multi_impl*>(m);
+    if (!mi) return EDSX_ERR_INVALID_PARAMETER;
+    if (partitioned) *partitioned = mi->m->partitioned() ? 1 : 0;
+    if (chains) *chains = mi->m->chains();
+    return EDSX_OK;
 }
 
 void edsx_set_timing(edsx_ctx* ctx, int enabled) { if (ctx) ctx->msa.set_timing(enabled != 0); }

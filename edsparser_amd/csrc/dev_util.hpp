@@ -137,6 +137,11 @@ __device__ __forceinline__ uint4 load16u(const uint8_t* p)
     __builtin_memcpy(&v, p, 16);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ void store16u(uint8_t* p, const uint4& v)   // 16 bytes to an arbitrarily aligned address
+{
+    U128u t{v.x, v.y, v.z, v.w};
+    __builtin_memcpy(p, &t, 16);
+}
 // partial load of n (<16) bytes, zero padded
 __device__ __forceinline__ uint4 load_partial(const uint8_t* p, int n)
 {
@@ -295,6 +300,93 @@ inline void device_scan_u64(const u64* in, u64* out, const u64* d_n, u64* d_tota
 inline void exclusive_scan_u64(const u64* in, u64* out, const u64* d_n, u64* d_total, u64* tmp, hipStream_t st)
 {
     device_scan_u64<0>(in, out, d_n, d_total, tmp, st);
+}
+
+// ---- N exclusive sums over arrays of the same length in ONE pass of the three kernels (the MSA planner scans two or
+// three size / flag arrays per step: a third of the launches and of the tail latencies).  tmp: N * (n / SCAN_TILE + 2) u64.
+template <int N> struct ScanSet { const u64* in[N]; u64* out[N]; u64* total[N]; };
+
+template <int N>
+static __global__ void k_mscan_tile_sums(ScanSet<N> a, const u64* __restrict__ n_ptr, u64* __restrict__ bsum)
+{
+    __shared__ u64 sh[SCAN_THREADS / 64];
+    const u64 n = *n_ptr;
+    const u64 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const u64 base = t * SCAN_TILE;
+        u64 s[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) s[k] = 0;
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const u64 idx = base + (u64)i * SCAN_THREADS + threadIdx.x;
+            if (idx < n) {
+#pragma unroll
+                for (int k = 0; k < N; k++) s[k] += a.in[k][idx];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const u64 r = block_reduce<0>(s[k], sh);
+            if (threadIdx.x == 0) bsum[(u64)k * (ntiles + 1) + t] = r;
+        }
+    }
+}
+template <int N>
+static __global__ void k_mscan_spine(ScanSet<N> a, u64* __restrict__ bsum, const u64* __restrict__ n_ptr)
+{
+    // N waves, one per array: a wave walks its tile sums 64 at a time (DPP-free shuffle scan)
+    const u64 n = *n_ptr;
+    const u64 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (k >= N) return;
+    u64* b = bsum + (u64)k * (ntiles + 1);
+    u64 carry = 0;
+    for (u64 base = 0; base < ntiles; base += 64) {
+        const u64 idx = base + lane;
+        const u64 v = idx < ntiles ? b[idx] : 0;
+        u64 incl = v;
+        for (int o = 1; o < 64; o <<= 1) { const u64 x = __shfl_up(incl, o, 64); if (lane >= o) incl += x; }
+        if (idx < ntiles) b[idx] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) *a.total[k] = carry;
+}
+template <int N>
+static __global__ void k_mscan_apply(ScanSet<N> a, const u64* __restrict__ n_ptr, const u64* __restrict__ bsum)
+{
+    __shared__ u64 wsum[N][SCAN_THREADS / 64];
+    const u64 n = *n_ptr;
+    const u64 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const u64 base = t * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+        u64 v[N][SCAN_ITEMS], excl[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            u64 s = 0;
+            for (int i = 0; i < SCAN_ITEMS; i++) { v[k][i] = (base + i < n) ? a.in[k][base + i] : 0; s += v[k][i]; }
+            u64 incl = s;
+            for (int o = 1; o < 64; o <<= 1) { const u64 x = __shfl_up(incl, o, 64); if (lane >= o) incl += x; }
+            excl[k] = incl - s;
+            if (lane == 63) wsum[k][w] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            u64 woff = 0;
+            for (int i = 0; i < w; i++) woff += wsum[k][i];
+            u64 run = bsum[(u64)k * (ntiles + 1) + t] + woff + excl[k];
+            for (int i = 0; i < SCAN_ITEMS; i++) { if (base + i < n) a.out[k][base + i] = run; run += v[k][i]; }
+        }
+        __syncthreads();
+    }
+}
+template <int N>
+inline void exclusive_scan_multi(const ScanSet<N>& a, const u64* d_n, u64* tmp, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_mscan_tile_sums<N>), dim3(1024), dim3(SCAN_THREADS), 0, st, a, d_n, tmp);
+    hipLaunchKernelGGL((k_mscan_spine<N>), dim3(1), dim3(64 * N), 0, st, a, tmp, d_n);
+    hipLaunchKernelGGL((k_mscan_apply<N>), dim3(1024), dim3(SCAN_THREADS), 0, st, a, d_n, tmp);
 }
 inline void inclusive_max_scan_u64(const u64* in, u64* out, const u64* d_n, u64* d_total, u64* tmp, hipStream_t st)
 {

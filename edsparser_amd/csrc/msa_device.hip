@@ -6,7 +6,7 @@
 //   pass 2 build_eds/leds_boundaries      :101-190 -> k_runstart_words .. k_write_segs
 //   pass 3 generate_output                :200-324 -> k_seg_meta, k_seg_count_fast (wave per segment, S <= 1024)
 //                                                     / k_seg_count (workgroup per segment), scans,
-//                                                     k_emit_common, k_emit_variant_fast / k_emit_variant
+//                                                     k_emit_fast2 / k_emit_fast / k_emit_variant (+ the common text in front)
 //
 // Data layout in HBM
 //   file image    the FASTA bytes as given (no repacking).  Row r's raw byte q lives at
@@ -290,6 +290,10 @@ struct K1Params {
     u32 fuse; u64* Fraw; u32* rec_info; uint8_t* recf; u32 recf_stride, recf_gid;
 };
 constexpr u32 FUSE_MAXW = 10;      // widest run grouped by the column scan (exact 3-bit-per-column keys in one dword)
+#ifndef EDSX_TAIL_WAVES
+#define EDSX_TAIL_WAVES 8
+#endif
+constexpr u32 TAIL_WAVES = EDSX_TAIL_WAVES;   // waves of a scan workgroup that copy / group its variant columns (the rest retire early)
 constexpr u32 CLIST = 2048;        // variant columns per tile in fused mode (the LDS image holds at most 64 KB / 32 B columns)
 // fused record (indexed by the vc slot of the run's first column): group ids, 2 bits each (dword l = rows 16l..16l+15)
 // for up to 4 strings, 4 bits each (two dwords per lane) for 5..16; then at recf_gid: u32 k | textlen << 8, then the
@@ -908,23 +912,27 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     bool overflow = false;
     {
         const u32 cap = p.cap_cols;
-        // LANEROWS: this thread's 16 rows x 16 columns, transposed in registers with v_perm_b32 (two
-        // rounds of byte interleaves per 4x4 block, 128 instructions): tr[c][k] = column c, rows 4k..4k+3
-        uint32_t tr[(HOLD && LANEROWS) ? 16 : 1][4];
-        if constexpr (HOLD && LANEROWS) {
-#define EDSX_T(C, COMP)                                                                            \
+        // LANEROWS: this thread's 16 rows x 16 columns are transposed in registers with v_perm_b32 (two rounds of byte
+        // interleaves per 4x4 block, 128 instructions), one dword component = four columns at a time: VISIT(I, a, b, c, d)
+        // gets column I as four dwords (rows 0..3, 4..7, 8..11, 12..15 of the thread).  The held chunks and a whole
+        // transposed copy are never live together.
+#define EDSX_TCOMP(C, COMP, VISIT) {                                                               \
+            uint32_t t4[4][4];                                                                     \
             _Pragma("unroll") for (int k4 = 0; k4 < 4; k4++) {                                    \
-                const uint32_t a0 = d[4 * k4].COMP, a1 = d[4 * k4 + 1].COMP, a2 = d[4 * k4 + 2].COMP, a3 = d[4 * k4 + 3].COMP; \
+                uint32_t a0 = d[4 * k4].COMP, a1 = d[4 * k4 + 1].COMP, a2 = d[4 * k4 + 2].COMP, a3 = d[4 * k4 + 3].COMP; \
+                /* opaque: or the optimiser hoists the permutes of all four components (they are the same in the fused */ \
+                /* and the batched path) in front of the branch, and the transposed copy is live beside the chunks again */ \
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));                        \
                 const uint32_t t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u); \
                 const uint32_t t2 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), t3 = __builtin_amdgcn_perm(a3, a2, 0x07030602u); \
-                tr[4 * C][k4] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);                       \
-                tr[4 * C + 1][k4] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);                   \
-                tr[4 * C + 2][k4] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);                   \
-                tr[4 * C + 3][k4] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);                   \
-            }
-            EDSX_T(0, x) EDSX_T(1, y) EDSX_T(2, z) EDSX_T(3, w)
-#undef EDSX_T
-        }
+                t4[0][k4] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);                           \
+                t4[1][k4] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);                           \
+                t4[2][k4] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);                           \
+                t4[3][k4] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);                           \
+            }                                                                                      \
+            VISIT(4 * C, t4[0][0], t4[0][1], t4[0][2], t4[0][3]) VISIT(4 * C + 1, t4[1][0], t4[1][1], t4[1][2], t4[1][3]) \
+            VISIT(4 * C + 2, t4[2][0], t4[2][1], t4[2][2], t4[2][3]) VISIT(4 * C + 3, t4[3][0], t4[3][1], t4[3][2], t4[3][3]) }
+#define EDSX_TALL(VISIT) EDSX_TCOMP(0, x, VISIT) EDSX_TCOMP(1, y, VISIT) EDSX_TCOMP(2, z, VISIT) EDSX_TCOMP(3, w, VISIT)
         bool fused_tile = false;
         if constexpr (HOLD && LANEROWS) fused_tile = p.fuse && nv && nv <= cap && nv <= CLIST;   // workgroup-uniform
         if (fused_tile) { if constexpr (HOLD && LANEROWS) {
@@ -932,14 +940,9 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
             if (V16) {
                 // (threads whose 16 rows do not exist write into the 16 bytes of slack behind the column's rows)
                 uint8_t* dst = colbuf + (size_t)pre_of(j) * p.Spad + (sub * 16u < p.Spad - 16u ? sub * 16u : p.Spad - 16u);
-#define EDSX_L(I)                                                                                 \
-                if (V16 & (1u << I)) {                                                            \
-                    *reinterpret_cast<uint4*>(dst) = make_uint4(tr[I][0], tr[I][1], tr[I][2], tr[I][3]); \
-                    dst += p.Spad;                                                                \
-                }
-                EDSX_L(0) EDSX_L(1) EDSX_L(2) EDSX_L(3) EDSX_L(4) EDSX_L(5) EDSX_L(6) EDSX_L(7)
-                EDSX_L(8) EDSX_L(9) EDSX_L(10) EDSX_L(11) EDSX_L(12) EDSX_L(13) EDSX_L(14) EDSX_L(15)
-#undef EDSX_L
+#define EDSX_VISIT(I, A, B, C_, D_) if (V16 & (1u << (I))) { *reinterpret_cast<uint4*>(dst) = make_uint4(A, B, C_, D_); dst += p.Spad; }
+                EDSX_TALL(EDSX_VISIT)
+#undef EDSX_VISIT
             }
             // ---- the runs of variant columns that lie inside the tile and are at most FUSE_MAXW wide are grouped here
             // (registered by the thread that owns their first column); every other variant column goes to vc
@@ -977,9 +980,16 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
             }
             if (!overflow) {
                 // ---- the other variant columns: LDS -> vc, one wave per column
+                // (Only the first TAIL_WAVES waves - one or two per SIMD - do this tail: the others end here, and a
+                // workgroup that is waiting for registers can start loading while these finish.)
+                const u32 wv = uniform32(tid >> 6);
+                if (wv >= TAIL_WAVES) {
+                    if (bad) atomicOr(&p.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));
+                    return;
+                }
                 {
                     const u32 nst = nst_sh, vec = p.Spad / 16u, ln = tid & 63u;
-                    for (u32 c = uniform32(tid >> 6); c < nst; c += T / 64) {
+                    for (u32 c = wv; c < nst; c += TAIL_WAVES) {
                         const u32 idx = clist[CLIST - 1u - c];
                         const uint8_t* src = colbuf + (size_t)idx * p.Spad;
                         uint8_t* g = p.vc + (slot_base + idx) * (u64)p.Spad;
@@ -992,30 +1002,33 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                 const u32 lane = tid & 63u, nl = (p.S + 15u) >> 4;
                 const uint4 vmask = fast_valid_mask(lane, p.S);
                 const u32 loff = lane * 16u < p.Spad - 16u ? lane * 16u : p.Spad - 16u;
-                for (u32 ci = uniform32(tid >> 6); ci < ncand; ci += T / 64)
+                for (u32 ci = wv; ci < ncand; ci += TAIL_WAVES)
                     fused_group_run<ROWS64>(p, colbuf, uniform32((u32)clist[ci]), slot_base, lane, vmask, nl, loff);
             }
         } } else
         for (u32 b0 = 0; b0 < nv || b0 == 0; b0 += cap) {
             if (V16 && nv) {
                 u32 idx = pre_of(j);
-                if constexpr (HOLD) {
+                if constexpr (HOLD && LANEROWS) {              // this thread's 16 rows are 16 consecutive bytes of the column
+#define EDSX_VISIT(I, A, B, C_, D_)                                                             \
+                    if (V16 & (1u << (I))) {                                                   \
+                        if (idx >= b0 && idx < b0 + cap && sub * 16u < p.S)      /* (rows past S: slack) */ \
+                            *reinterpret_cast<uint4*>(colbuf + (size_t)(idx - b0) * p.Spad + sub * 16) = make_uint4(A, B, C_, D_); \
+                        idx++;                                                                 \
+                    }
+                    EDSX_TALL(EDSX_VISIT)
+#undef EDSX_VISIT
+                } else if constexpr (HOLD) {
 #define EDSX_X(I)                                                                              \
                     if (V16 & (1u << I)) {                                                     \
                         if (idx >= b0 && idx < b0 + cap) {                                     \
                             uint8_t* dst = colbuf + (size_t)(idx - b0) * p.Spad;               \
-                            if constexpr (LANEROWS) { /* this thread's 16 rows are 16 consecutive bytes */  \
-                                constexpr int TI = LANEROWS ? I : 0; /* of the column (rows past S: slack) */    \
-                                if (sub * 16u < p.S)                                            \
-                                    *reinterpret_cast<uint4*>(dst + sub * 16) = make_uint4(tr[TI][0], tr[TI][1], tr[TI][2], tr[TI][3]); \
-                            } else {                                                           \
-                                _Pragma("unroll") for (int it = 0; it < RPT; it++) {           \
-                                    const u32 r = sub + it * RI;                               \
-                                    if (r < p.S) {                                             \
-                                        const u32 ch = byte_at<I>(d[it]);                      \
-                                        if (ch == '\n') bad = 1;                               \
-                                        dst[r] = (uint8_t)ch;                                  \
-                                    }                                                          \
+                            _Pragma("unroll") for (int it = 0; it < RPT; it++) {               \
+                                const u32 r = sub + it * RI;                                   \
+                                if (r < p.S) {                                                 \
+                                    const u32 ch = byte_at<I>(d[it]);                          \
+                                    if (ch == '\n') bad = 1;                                   \
+                                    dst[r] = (uint8_t)ch;                                      \
                                 }                                                              \
                             }                                                                  \
                         }                                                                      \
@@ -1456,9 +1469,93 @@ struct SegParams {
     u32 stage_cols = 0, stage_off = 0;        // LDS column staging: capacity in columns, byte offset in the dynamic LDS
     // grouping cache (count -> emit): item `it` of the list (or segment `it`) keeps k, its group ids and first rows
     uint8_t* gcache = nullptr; u64 gcache_cap = 0; u32 gcache_stride = 0;
+    u64* long_list = nullptr; u64* long_count = nullptr;   // common segments for k_emit_common_long (see common_is_long)
 };
 // cache entry: u32 k, pad; u16 gid[S (rounded up to 8)]; u32 rep_row[S]
 __host__ __device__ inline u32 gcache_stride_of(u32 S) { return 16u + ((S + 7u) & ~7u) * 2u + S * 4u; }
+
+// ---- common segments (msa_transforms.cpp:245-258: "{" + the reference row's text + "}" and "{0}") ---------------------
+// A thread per common segment (they alternate with the variant ones): four coalesced table reads, then the few
+// reference bytes as unaligned 16-byte copies.  Segments longer than LONG_COMMON columns are left to k_emit_common_long
+// (a workgroup per segment, all workgroups for the very long ones).
+constexpr u64 LONG_COMMON = 512, HUGE_COMMON = 1u << 20;
+template <int N> struct __attribute__((packed, aligned(1))) PackedBytes { uint8_t b[N]; };
+template <int N> __device__ __forceinline__ void store_small(uint8_t* p, u64 v)   // the low N (2, 4, 8) bytes of v, any alignment
+{
+    PackedBytes<N> t;
+    __builtin_memcpy(&t, &v, N);
+    __builtin_memcpy(p, &t, N);
+}
+__device__ __forceinline__ bool common_is_long(u64 ncol) { return ncol > LONG_COMMON; }
+
+__global__ void __launch_bounds__(256) k_emit_common_seg(MsaView mv, const u64* __restrict__ seg_start, const u64* __restrict__ nseg_ptr,
+                                                         const u64* __restrict__ eds_off, const u64* __restrict__ seds_off,
+                                                         uint8_t* __restrict__ eds, uint8_t* __restrict__ seds)
+{
+    const u64 nseg = *nseg_ptr, p0 = mv.vbit(0) ? 0 : 1;
+    const uint8_t* row0 = mv.file + mv.row_start[0];
+    for (u64 seg = (1 - p0) + 2 * (blockIdx.x * (u64)blockDim.x + threadIdx.x); seg < nseg; seg += 2 * (u64)gridDim.x * blockDim.x) {
+        const u64 a = seg_start[seg], clen = seg_start[seg + 1] - a;
+        if (common_is_long(clen)) continue;
+        uint8_t* e = eds + eds_off[seg];
+        uint8_t* q = seds + seds_off[seg];
+        store_small<2>(q, (u32)'{' | ((u32)'0' << 8)); q[2] = '}';
+        e[clen + 1] = '}';
+        if (mv.lw == 0 && clen >= 16) {
+            e[0] = '{';
+            for (u64 o = 0; o < clen; o += 16) {
+                const u64 oo = o + 16 <= clen ? o : clen - 16;        // the last piece ends with the segment (it overlaps the one before)
+                store16u(e + 1 + oo, load16u(row0 + a + oo));
+            }
+        } else if (mv.lw == 0) {
+            // "{" + up to 15 letters: one 16-byte load (row 0 is followed by more of the file: never past its end), then
+            // the clen + 1 bytes as 16 / 8 + 4 + 2 + 1 byte stores
+            const uint4 v = load16u(row0 + a);
+            u64 lo = ((u64)v.y << 32) | v.x, hi = ((u64)v.w << 32) | v.z;
+            hi = (hi << 8) | (lo >> 56); lo = (lo << 8) | (u64)'{';
+            const u32 m = (u32)clen + 1u;
+            if (m == 16u) store16u(e, make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)));
+            else {
+                uint8_t* d = e;
+                if (m & 8u) { store_small<8>(d, lo); d += 8; lo = hi; }
+                if (m & 4u) { store_small<4>(d, lo); d += 4; lo >>= 32; }
+                if (m & 2u) { store_small<2>(d, lo); d += 2; lo >>= 16; }
+                if (m & 1u) *d = (uint8_t)lo;
+            }
+        } else {
+            e[0] = '{';
+            for (u64 o = 0; o < clen; o++) e[1 + o] = (uint8_t)mv.ref_byte(a + o);
+        }
+    }
+}
+
+// the long ones: a workgroup per listed segment; every workgroup takes its share of a segment of more than HUGE_COMMON columns
+__global__ void __launch_bounds__(256) k_emit_common_long(MsaView mv, const u64* __restrict__ seg_start, const u64* __restrict__ eds_off,
+                                                          const u64* __restrict__ seds_off, const u64* __restrict__ list,
+                                                          const u64* __restrict__ list_n, uint8_t* __restrict__ eds, uint8_t* __restrict__ seds)
+{
+    const u64 n = *list_n;
+    const uint8_t* row0 = mv.file + mv.row_start[0];
+    for (u64 i = 0; i < n; i++) {
+        const u64 seg = list[i], a = seg_start[seg], clen = seg_start[seg + 1] - a;
+        const bool huge = clen > HUGE_COMMON;
+        if (!huge && i % gridDim.x != blockIdx.x) continue;
+        const u64 t = huge ? blockIdx.x * (u64)blockDim.x + threadIdx.x : threadIdx.x, nt = huge ? (u64)gridDim.x * blockDim.x : blockDim.x;
+        uint8_t* e = eds + eds_off[seg];
+        if (t == 0) {
+            e[0] = '{'; e[clen + 1] = '}';
+            uint8_t* q = seds + seds_off[seg];
+            q[0] = '{'; q[1] = '0'; q[2] = '}';
+        }
+        if (mv.lw == 0) {
+            for (u64 o = 16 * t; o < clen; o += 16 * nt) {               // (clen > LONG_COMMON >= 16)
+                const u64 oo = o + 16 <= clen ? o : clen - 16;
+                store16u(e + 1 + oo, load16u(row0 + a + oo));
+            }
+        } else
+            for (u64 o = t; o < clen; o += nt) e[1 + o] = (uint8_t)mv.ref_byte(a + o);
+    }
+}
 
 // K3: per-segment output sizes.  common: "{" ref "}" and "{0}"; variant: see generate_output.
 __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
@@ -1473,8 +1570,10 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
     const u64 nseg = *p.nseg_ptr, p0 = p.mv.vbit(0) ? 0 : 1;
     if (!p.list)
         for (u64 seg = (1 - p0) + 2 * (blockIdx.x * (u64)GT + threadIdx.x); seg < nseg; seg += 2 * (u64)gridDim.x * GT) {
-            p.eds_len[seg] = 2 + (p.seg_start[seg + 1] - p.seg_start[seg]);
+            const u64 ncol = p.seg_start[seg + 1] - p.seg_start[seg];
+            p.eds_len[seg] = 2 + ncol;
             p.seds_len[seg] = 3;
+            if (common_is_long(ncol)) p.long_list[atomicAdd(p.long_count, 1ull)] = seg;
         }
     const u64 nitems = p.list ? *p.list_n : (nseg > p0 ? (nseg - p0 + 1) / 2 : 0);
     for (u64 it = blockIdx.x; it < nitems; it += gridDim.x) {
@@ -1506,8 +1605,7 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// K5a: common-segment text.  One wave per 64-column word, lane = column.
-//   msa_transforms.cpp:245-258
+// K5: parameters of the generic emitter
 // ---------------------------------------------------------------------------------------------
 struct EmitParams {
     MsaView mv; const u64* seg_start; const u64* nseg_ptr; const u64* Hseg; const u64* segbase;
@@ -1515,55 +1613,8 @@ struct EmitParams {
     const u64* list; const u64* list_n;
     u32 stage_cols = 0, stage_off = 0;
     const uint8_t* gcache = nullptr; u64 gcache_cap = 0; u32 gcache_stride = 0;      // see SegParams
+    const u64* list2 = nullptr; const u64* list2_n = nullptr; const uint8_t* gcache2 = nullptr;   // a second work list behind the first
 };
-
-__global__ void __launch_bounds__(256) k_emit_common(EmitParams p)
-{
-    // A column's byte sits behind three dependent loads (segment ordinal -> segment start -> variant bit / text offset):
-    // a wave takes U words per trip and issues each level of the chain for all of them before the first store.
-    constexpr int U = 4;
-    const u32 lane = threadIdx.x & 63;
-    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
-    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 w0 = wave; w0 < p.nwords; w0 += nwaves * U) {
-        // (every load below is unconditional - lanes and words past the end read word 0 / the last column - so that the
-        // compiler keeps the U loads of a level together instead of one branch and wait per word)
-        u64 c[U], seg[U], a[U], e[U], pos[U], so[U];
-        u32 ch[U];
-        bool on[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const u64 w = w0 + (u64)u * nwaves;
-            const u64 ws = w < p.nwords ? w : 0;
-            const u64 cr = ws * 64 + lane;
-            on[u] = w < p.nwords && cr < p.mv.L;
-            c[u] = cr < p.mv.L ? cr : p.mv.L - 1;
-            const u64 below = p.Hseg[ws] & ((2ull << (c[u] & 63)) - 1ull);
-            seg[u] = p.segbase[ws] + __builtin_popcountll(below) - 1;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) a[u] = p.seg_start[seg[u]];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            on[u] = on[u] && !p.mv.vbit(a[u]);                // variant segment: k_emit_variant
-            e[u] = p.seg_start[seg[u] + 1];
-            pos[u] = p.eds_off[seg[u]] + 1 + (c[u] - a[u]);
-            ch[u] = p.mv.ref_byte(c[u]);
-            so[u] = p.seds_off[seg[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (!on[u]) continue;
-            p.eds[pos[u]] = (uint8_t)ch[u];
-            if (c[u] == a[u]) {
-                p.eds[pos[u] - 1] = '{';
-                uint8_t* s = p.seds + so[u];
-                s[0] = '{'; s[1] = '0'; s[2] = '}';
-            }
-            if (c[u] == e[u] - 1) p.eds[pos[u] + 1] = '}';
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // K5b: variant-segment text.  msa_transforms.cpp:297-317.
@@ -1582,16 +1633,19 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
     SegLds lds(lds_raw, S);
     if (mv.hdr->status) return;
     const u64 nseg = *p.nseg_ptr, p0 = mv.vbit(0) ? 0 : 1;      // items as in k_seg_count
-    const u64 nitems = p.list ? *p.list_n : (nseg > p0 ? (nseg - p0 + 1) / 2 : 0);
+    const u64 n1 = p.list ? *p.list_n : (nseg > p0 ? (nseg - p0 + 1) / 2 : 0);
+    const u64 nitems = n1 + (p.list2 ? *p.list2_n : 0);
     const u32 lane = threadIdx.x & 63;
-    for (u64 it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const u64 seg = p.list ? p.list[it] : p0 + 2 * it;
+    for (u64 it0 = blockIdx.x; it0 < nitems; it0 += gridDim.x) {
+        const bool second = it0 >= n1;                       // (workgroup-uniform)
+        const u64 it = second ? it0 - n1 : it0;
+        const u64 seg = second ? p.list2[it] : p.list ? p.list[it] : p0 + 2 * it;
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         u32 cap = p.stage_cols;
         const uint8_t* st = stage_columns(mv, a, b, p.stage_cols ? lds_raw + p.stage_off : nullptr, cap, &rep_sh);
         u32 k;
         if (it < p.gcache_cap) {                             // grouped by k_seg_count already
-            const uint8_t* ce = p.gcache + it * (u64)p.gcache_stride;
+            const uint8_t* ce = (second ? p.gcache2 : p.gcache) + it * (u64)p.gcache_stride;
             const uint16_t* cg = reinterpret_cast<const uint16_t*>(ce + 16);
             const u32* cr = reinterpret_cast<const u32*>(ce + 16 + ((S + 7u) & ~7u) * 2u);
             k = *reinterpret_cast<const u32*>(ce);
@@ -1794,6 +1848,7 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
             p.eds_len[seg] = 2 + (b - a);
             p.seds_len[seg] = 3;
             p.segmeta[seg] = 0;
+            if (common_is_long(b - a)) p.long_list[atomicAdd(p.long_count, 1ull)] = seg;
             break;
         }
         const u64 vi = (seg - p0) >> 1;
@@ -1826,31 +1881,29 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
         } while (false);
         if (seg < nseg && mv.vbit(p.seg_start[seg])) {
             const u64 vi = (seg - p0) >> 1;
-            p.cnt_meta[vi] = work_cm; p.cnt_flag[vi] = work_cm ? 1 : 0; p.wide_flag[vi] = work_wide;
+            // light list: up to ten pure variant columns; heavy list: 11..64 columns or common columns inside (the two
+            // grouping kernels run side by side)
+            const bool heavy = work_cm && ((work_cm & CNT_MIXED) || ((work_cm >> 48) & 0xffu) > 10u);
+            p.cnt_meta[vi] = work_cm; p.cnt_flag[vi] = work_cm && !heavy ? 1 : 0; p.heavy_flag[vi] = heavy ? 1 : 0;
+            p.wide_flag[vi] = work_wide;
         }
-    }
-}
-
-// the heavy grouping kernel's list: the items the light one flagged
-__global__ void __launch_bounds__(256) k_heavy_scatter(FastParams p, const u64* __restrict__ pos)
-{
-    if (p.mv.hdr->status) return;
-    const u64 n = *p.cnt_n, tot = *p.heavy_n;
-    for (u64 it = blockIdx.x * (u64)blockDim.x + threadIdx.x; it < n; it += (u64)gridDim.x * blockDim.x) {
-        const u64 a = pos[it], b = it + 1 < n ? pos[it + 1] : tot;
-        if (a != b) { p.heavy_vi[a] = p.cnt_vi[it]; p.heavy_cm[a] = p.cnt_cm[it]; }
     }
 }
 
 // work list of the grouping kernel: the variant segments with a column descriptor, compacted with a scan of the
 // flags (no atomics: 4 M appends to one counter would take milliseconds)
-__global__ void __launch_bounds__(256) k_work_scatter(FastParams p, const u64* __restrict__ pos, const u64* __restrict__ nvs_ptr)
+__global__ void __launch_bounds__(256) k_work_scatter(FastParams p, const u64* __restrict__ pos, const u64* __restrict__ hpos,
+                                                      const u64* __restrict__ nvs_ptr)
 {
     if (p.mv.hdr->status) return;
     const u64 nvs = *nvs_ptr;
     for (u64 vi = blockIdx.x * (u64)blockDim.x + threadIdx.x; vi < nvs; vi += (u64)gridDim.x * blockDim.x) {
         const u64 cm = p.cnt_meta[vi];
-        if (cm) { const u64 i = pos[vi]; p.cnt_vi[i] = vi; p.cnt_cm[i] = cm; }
+        if (cm) {
+            const bool heavy = (cm & CNT_MIXED) || ((cm >> 48) & 0xffu) > 10u;
+            if (heavy) { const u64 i = hpos[vi]; p.heavy_vi[i] = vi; p.heavy_cm[i] = cm; }
+            else { const u64 i = pos[vi]; p.cnt_vi[i] = vi; p.cnt_cm[i] = cm; }
+        }
         const u64 wpos = p.wide_flag[vi];               // (exclusive scan in place: position; a set flag = the next one is larger)
         const u64 wnext = vi + 1 < nvs ? p.wide_flag[vi + 1] : *p.wide_count;
         if (wnext != wpos) p.wide_list[wpos] = vi;
@@ -2121,7 +2174,8 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
 // instantiation (one column / up to ten DNA columns) hands what it cannot do to the heavy one's list.
 // The descriptor and the first column of the wave's next segment are requested one iteration ahead.
 template <bool HEAVY>
-__global__ void __launch_bounds__(256, HEAVY ? 3 : 4) k_seg_group(FastParams p)
+__global__ void __launch_bounds__(256, HEAVY ? 3 : 4) k_seg_group(FastParams p, const u64* __restrict__ lvi, const u64* __restrict__ lcm,
+                                                                  const u64* __restrict__ n_ptr)
 {
     __shared__ uint8_t strs_all[HEAVY ? 4 * 8192 : 4];
     uint8_t* strs = strs_all + (HEAVY ? (threadIdx.x >> 6) * 8192u : 0u);
@@ -2129,9 +2183,7 @@ __global__ void __launch_bounds__(256, HEAVY ? 3 : 4) k_seg_group(FastParams p)
     if (mv.hdr->status) return;
     const u32 lane = threadIdx.x & 63;
     const u64 p0 = mv.vbit(0) ? 0 : 1;
-    const u64 n = HEAVY ? *p.heavy_n : *p.cnt_n;
-    const u64* lvi = HEAVY ? p.heavy_vi : p.cnt_vi;
-    const u64* lcm = HEAVY ? p.heavy_cm : p.cnt_cm;
+    const u64 n = *n_ptr;
     const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
     const uint4 vmask = fast_valid_mask(lane, mv.S);
     const u32 nl = (mv.S + 15u) >> 4;                          // lanes that own rows
@@ -2181,7 +2233,10 @@ __global__ void __launch_bounds__(256, HEAVY ? 3 : 4) k_seg_group(FastParams p)
         } else if (lane == 0 && !(!HEAVY && ok == 2)) {
             p.slow_list2[atomicAdd(p.slow_count2, 1ull)] = seg;       // the generic kernels take it
         }
-        if (!HEAVY && lane == 0) p.cnt_flag[it] = ok == 2 ? 1 : 0;   // for the heavy instantiation (its list: a scan of these flags)
+        if (!HEAVY && ok == 2 && lane == 0) {                       // another alphabet: the second heavy pass takes it
+            const u64 i = atomicAdd(p.heavy2_n, 1ull);
+            p.heavy2_vi[i] = vi; p.heavy2_cm[i] = cmeta;
+        }
         const u64 cmeta_nn = it + 2 * nw < n ? uniform64(cm_v) : 0, vi_nn = it + 2 * nw < n ? uniform64(vi_v) : 0;
         it += nw; cmeta = cmeta_n; cmeta_n = cmeta_nn; vi = vi_n; vi_n = vi_nn; col = col_n; rb = rb_n;
     }
@@ -2212,11 +2267,6 @@ template <int OFF> __device__ __forceinline__ void lds_put1(u32 a, u32 v)
 __device__ __forceinline__ u32 lane_read(u32 v, u32 src_lane)       // v of lane src_lane (per-lane source)
 {
     return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
-}
-__device__ __forceinline__ void store16u(uint8_t* p, const uint4& v)   // 16 bytes to an arbitrarily aligned address
-{
-    U128u t{v.x, v.y, v.z, v.w};
-    __builtin_memcpy(p, &t, 16);
 }
 
 // Writes the id lists "{i,i,..}{i,..}.." of k (<= 4 / <= 16) strings of one segment to gseds (msa_transforms.cpp:305-316)
@@ -3036,7 +3086,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     cnt_.ensure(8 * (nwords + 1));
     wbase_.ensure(8 * (nwords + 1));
     segbase_.ensure(8 * (nwords + 1));
-    scan_tmp_.ensure(8 * ((L + 2) / SCAN_TILE + 2));
+    scan_tmp_.ensure(8 * 3 * ((L + 2) / SCAN_TILE + 4));      // up to three arrays per pass (exclusive_scan_multi)
     run_start_.ensure(8 * (L + 2));
     if (l) { flag_.ensure(8 * (L + 2)); seg_start_.ensure(8 * (L + 2)); }
     eds_len_.ensure(8 * (L + 2));
@@ -3158,6 +3208,9 @@ void MsaPipeline::plan_body(hipStream_t st)
     sp.mv = mv_; sp.seg_start = seg_start; sp.nseg_ptr = d_nseg; sp.eds_len = eds_len_.as<u64>();
     sp.seds_len = seds_len_.as<u64>(); sp.tok_total = tok_total; sp.list = nullptr; sp.list_n = nullptr;
     sp.stage_cols = stage_cols_; sp.stage_off = stage_off_;
+    long_list_.ensure(8 * (L / LONG_COMMON + 4));             // the long common segments
+    sp.long_list = long_list_.as<u64>(); sp.long_count = &dh->long_n;
+    EDSX_HIP(hipMemsetAsync(&dh->long_n, 0, sizeof(u64), st));
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_count),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     if (fast_) {
@@ -3165,7 +3218,7 @@ void MsaPipeline::plan_body(hipStream_t st)
         // list 1: too wide or mixed segments (k_seg_meta), list 2: those the grouping kernel gives up on; together
         // at most all variant segments (<= L/2 + 1)
         slow_list_.ensure(8 * 3 * (L / 2 + 4));            // + the wide emitter's list
-        cnt_list_.ensure(8 * 7 * (L / 2 + 4));                // work lists of the grouping kernels (ordinal + column descriptor, twice), descriptor and flag per variant segment
+        cnt_list_.ensure(8 * 10 * (L / 2 + 4));               // work lists of the grouping kernels (ordinal + column descriptor, three times), descriptor and flags per variant segment
         fp_.mv = mv_; fp_.seg_start = seg_start; fp_.nseg_ptr = d_nseg; fp_.segmeta = segmeta_.as<u64>();
         fp_.eds_len = eds_len_.as<u64>(); fp_.seds_len = seds_len_.as<u64>();
         fp_.slow_list = slow_list_.as<u64>(); fp_.slow_count = &dh->slow_n;
@@ -3173,6 +3226,8 @@ void MsaPipeline::plan_body(hipStream_t st)
         fp_.cnt_vi = cnt_list_.as<u64>(); fp_.cnt_cm = fp_.cnt_vi + (L / 2 + 4); fp_.cnt_n = &dh->cnt_n;
         fp_.heavy_vi = fp_.cnt_cm + (L / 2 + 4); fp_.heavy_cm = fp_.heavy_vi + (L / 2 + 4); fp_.heavy_n = &dh->heavy_n;
         fp_.cnt_meta = fp_.heavy_cm + (L / 2 + 4); fp_.cnt_flag = fp_.cnt_meta + (L / 2 + 4); fp_.wide_flag = fp_.cnt_flag + (L / 2 + 4);
+        fp_.heavy_flag = fp_.wide_flag + (L / 2 + 4); fp_.heavy2_vi = fp_.heavy_flag + (L / 2 + 4); fp_.heavy2_cm = fp_.heavy2_vi + (L / 2 + 4);
+        fp_.heavy2_n = &dh->heavy2_n;
         fp_.wide_list = slow_list_.as<u64>() + 2 * (L / 2 + 4); fp_.wide_count = &dh->wide_n;
         fp_.eds = nullptr; fp_.seds = nullptr; fp_.tok_total = tok_total;
         // one record per variant segment; there are at most as many as variant columns
@@ -3181,18 +3236,27 @@ void MsaPipeline::plan_body(hipStream_t st)
         fp_.rec = rec_.as<uint8_t>();
         fp_.Fraw = fuse_ ? fraw_.as<u64>() : nullptr; fp_.rec_info = rec_info_.as<u32>();
         fp_.recf = recf_.as<uint8_t>(); fp_.recf_stride = recf_stride_; fp_.recf_gid = recf_gid_;
+        fp_.long_list = sp.long_list; fp_.long_count = sp.long_count;
         EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, 2 * sizeof(u64), st));
         EDSX_HIP(hipMemsetAsync(&dh->wide_n, 0, 3 * sizeof(u64), st));     // (wide_n is then set by scan_wide, and added to by k_seg_group)
+        EDSX_HIP(hipMemsetAsync(&dh->heavy2_n, 0, sizeof(u64), st));
         TIMED("k_seg_meta", st, hipLaunchKernelGGL(k_seg_meta, dim3(4096), dim3(256), 0, st, fp_));
-        TIMED("scan_work", st, exclusive_scan_u64(fp_.cnt_flag, fp_.cnt_flag, &dh->nvs, &dh->cnt_n, scan_tmp_.as<u64>(), st));
-        TIMED("scan_wide", st, exclusive_scan_u64(fp_.wide_flag, fp_.wide_flag, &dh->nvs, &dh->wide_n, scan_tmp_.as<u64>(), st));
-        TIMED("k_work_scatter", st, hipLaunchKernelGGL(k_work_scatter, dim3(2048), dim3(256), 0, st, fp_, fp_.cnt_flag, &dh->nvs));
+        {   // list positions of the light / heavy grouping lists and of the wide emitter's list: one pass
+            ScanSet<3> ss{{fp_.cnt_flag, fp_.heavy_flag, fp_.wide_flag}, {fp_.cnt_flag, fp_.heavy_flag, fp_.wide_flag},
+                          {&dh->cnt_n, &dh->heavy_n, &dh->wide_n}};
+            TIMED("scan_lists", st, exclusive_scan_multi<3>(ss, &dh->nvs, scan_tmp_.as<u64>(), st));
+        }
+        TIMED("k_work_scatter", st, hipLaunchKernelGGL(k_work_scatter, dim3(2048), dim3(256), 0, st, fp_, fp_.cnt_flag, fp_.heavy_flag, &dh->nvs));
+        // (The light and the heavy grouping kernel and the generic count are independent, but side by side on three
+        // streams they only share the machine - measured in round 3: 1.85 ms for the three against 1.33 + 0.41 + 0.01 one
+        // after the other - so they run in line.)
         TIMED("k_seg_group", st, hipLaunchKernelGGL(k_seg_group<false>, dim3(persistent_grid(
-                  reinterpret_cast<const void*>(k_seg_group<false>), 256, 0)), dim3(256), 0, st, fp_));
-        TIMED("scan_heavy", st, exclusive_scan_u64(fp_.cnt_flag, fp_.cnt_flag, &dh->cnt_n, &dh->heavy_n, scan_tmp_.as<u64>(), st));
-        TIMED("k_heavy_scatter", st, hipLaunchKernelGGL(k_heavy_scatter, dim3(2048), dim3(256), 0, st, fp_, fp_.cnt_flag));
+                  reinterpret_cast<const void*>(k_seg_group<false>), 256, 0)), dim3(256), 0, st, fp_, fp_.cnt_vi, fp_.cnt_cm, &dh->cnt_n));
         TIMED("k_seg_group_heavy", st, hipLaunchKernelGGL(k_seg_group<true>, dim3(persistent_grid(
-                  reinterpret_cast<const void*>(k_seg_group<true>), 256, 0)), dim3(256), 0, st, fp_));
+                  reinterpret_cast<const void*>(k_seg_group<true>), 256, 0)), dim3(256), 0, st, fp_, fp_.heavy_vi, fp_.heavy_cm, &dh->heavy_n));
+        // second heavy pass: what the light kernel could not group (alphabets other than {A,C,G,T,N,-}; usually nothing)
+        TIMED("k_seg_group_heavy2", st, hipLaunchKernelGGL(k_seg_group<true>, dim3(persistent_grid(
+                  reinterpret_cast<const void*>(k_seg_group<true>), 256, 0)), dim3(256), 0, st, fp_, fp_.heavy2_vi, fp_.heavy2_cm, &dh->heavy2_n));
         sp.gcache_stride = gc_stride_; sp.gcache_cap = gc_region_ / gc_stride_;
         sp.list = fp_.slow_list; sp.list_n = fp_.slow_count; sp.gcache = gcache_.as<uint8_t>();
         TIMED("k_seg_count_slow", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
@@ -3202,10 +3266,10 @@ void MsaPipeline::plan_body(hipStream_t st)
         sp.gcache_stride = gc_stride_; sp.gcache_cap = 2 * gc_region_ / gc_stride_; sp.gcache = gcache_.as<uint8_t>();
         TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
     }
-    TIMED("scan_eds", st, exclusive_scan_u64(eds_len_.as<u64>(), eds_len_.as<u64>(), d_nseg, &dh->E,
-                                             scan_tmp_.as<u64>(), st));
-    TIMED("scan_seds", st, exclusive_scan_u64(seds_len_.as<u64>(), seds_len_.as<u64>(), d_nseg, &dh->Q,
-                                              scan_tmp_.as<u64>(), st));
+    {   // text offsets of both outputs: one pass
+        ScanSet<2> ss{{eds_len_.as<u64>(), seds_len_.as<u64>()}, {eds_len_.as<u64>(), seds_len_.as<u64>()}, {&dh->E, &dh->Q}};
+        TIMED("scan_text", st, exclusive_scan_multi<2>(ss, d_nseg, scan_tmp_.as<u64>(), st));
+    }
 }
 
 // workgroups that are resident at once: one persistent workgroup per slot
@@ -3321,28 +3385,29 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
     ep.stage_cols = stage_cols_; ep.stage_off = stage_off_;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_emit_variant),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
+    auto launch_common = [&](hipStream_t s) {                 // the common segments: "{" reference text "}" and "{0}"
+        TIMED("k_emit_common_seg", s, hipLaunchKernelGGL(k_emit_common_seg, dim3(4096), dim3(256), 0, s, mv_, seg_start_p_, nseg_p_,
+                                                         eds_len_.as<u64>(), seds_len_.as<u64>(), d_eds, d_seds));
+        TIMED("k_emit_common_long", s, hipLaunchKernelGGL(k_emit_common_long, dim3(512), dim3(256), 0, s, mv_, seg_start_p_,
+                                                          eds_len_.as<u64>(), seds_len_.as<u64>(), long_list_.as<u64>(),
+                                                          &hdr_.as<MsaHdr>()->long_n, d_eds, d_seds));
+    };
     if (fast_) {
-        // (Running the common text, the wide and the generic emitters beside the main emitter on a second stream was
-        // measured: the persistent main emitter fills every CU, the side kernels only slow it down - 41.0 vs 39.7 ms.)
         FastParams fp = fp_;
         fp.eds = d_eds; fp.seds = d_seds;
         auto launch_emit = [&](auto kern, const char* name) {
             TIMED(name, st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
                                                dim3(256), 0, st, fp));
         };
-        // (side kernels that do not wait for the main emitter, on low-priority streams: measured in round 2, inside the noise)
+        // The main emitter fills the machine (beside it the small emitters only slow it down: measured in rounds 1 and 3);
+        // behind it the wide emitter, the generic emitter (a few hundred workgroup-sized segments) and the common text
+        // run side by side on three streams.
         launch_emit(k_emit_fast2, "k_emit_fast");
-        // The small emitters behind it are latency-bound (a few hundred workgroups each, dependent loads): they run
-        // side by side on streams of their own and join the caller's stream at the end.
-        hipStream_t s1 = st, s2 = st;
-        {
-            ensure_side_streams();
-            s1 = side_[0]; s2 = side_[1];
-            EDSX_HIP(hipEventRecord(side_ev_[0], st));
-            EDSX_HIP(hipStreamWaitEvent(s1, side_ev_[0], 0));
-            EDSX_HIP(hipStreamWaitEvent(s2, side_ev_[0], 0));
-        }
-        TIMED("k_emit_common", s1, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, s1, ep));
+        ensure_side_streams();
+        hipStream_t s1 = side_[0], s2 = side_[1];
+        EDSX_HIP(hipEventRecord(side_ev_[0], st));
+        EDSX_HIP(hipStreamWaitEvent(s1, side_ev_[0], 0));
+        EDSX_HIP(hipStreamWaitEvent(s2, side_ev_[0], 0));
         {
             auto launch_wide = [&](auto kern) {
                 TIMED("k_emit_fast_wide", st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
@@ -3353,17 +3418,15 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
         }
         ep.gcache_stride = gc_stride_; ep.gcache_cap = gc_region_ / gc_stride_;
         ep.list = fp_.slow_list; ep.list_n = fp_.slow_count; ep.gcache = gcache_.as<uint8_t>();
+        ep.list2 = fp_.slow_list2; ep.list2_n = fp_.slow_count2; ep.gcache2 = gcache_.as<uint8_t>() + gc_region_;
         TIMED("k_emit_variant_slow", s2, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
-        ep.list = fp_.slow_list2; ep.list_n = fp_.slow_count2; ep.gcache = gcache_.as<uint8_t>() + gc_region_;
-        TIMED("k_emit_variant_slow2", s2, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
-        {
-            EDSX_HIP(hipEventRecord(side_ev_[1], s1));
-            EDSX_HIP(hipEventRecord(side_ev_[2], s2));
-            EDSX_HIP(hipStreamWaitEvent(st, side_ev_[1], 0));
-            EDSX_HIP(hipStreamWaitEvent(st, side_ev_[2], 0));
-        }
+        launch_common(s1);
+        EDSX_HIP(hipEventRecord(side_ev_[1], s1));
+        EDSX_HIP(hipEventRecord(side_ev_[2], s2));
+        EDSX_HIP(hipStreamWaitEvent(st, side_ev_[1], 0));
+        EDSX_HIP(hipStreamWaitEvent(st, side_ev_[2], 0));
     } else {
-        TIMED("k_emit_common", st, hipLaunchKernelGGL(k_emit_common, dim3(2048), dim3(256), 0, st, ep));
+        launch_common(st);
         ep.gcache_stride = gc_stride_; ep.gcache_cap = 2 * gc_region_ / gc_stride_; ep.gcache = gcache_.as<uint8_t>();
         TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
     }

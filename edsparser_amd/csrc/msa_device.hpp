@@ -89,6 +89,8 @@ struct MsaHdr {
     u64 wide_n;        // variant segments of 5..64 strings (k_seg_group -> wide emitter)
     u64 cnt_n, heavy_n; // lengths of the grouping kernels' work lists (adjacent to wide_n: cleared together)
     u64 nvs;           // number of variant segments
+    u64 long_n;        // common segments the variant emitters leave to k_emit_common_long (very long ones, and a final one)
+    u64 heavy2_n;      // segments the light grouping kernel hands to a second heavy pass (other alphabets)
 };
 
 // One vc column holds the bytes of one variant column in NATURAL row order: byte r = row r, pitch =
@@ -128,11 +130,14 @@ struct FastParams {
     u64* wide_flag;                         // per variant segment: grouped by the column scan with 5..16 strings (-> wide emitter's list)
     u64* cnt_meta; u64* cnt_flag;           // per variant segment: column descriptor (0: not for k_seg_group), flag / list position
     u64* cnt_vi; u64* cnt_cm; u64* cnt_n;   // work list of k_seg_group: ordinal among the variant segments, column descriptor
-    u64* heavy_vi; u64* heavy_cm; u64* heavy_n;   // ... of its heavy instantiation (wide or non-DNA segments)
+    u64* heavy_vi; u64* heavy_cm; u64* heavy_n;   // ... of its heavy instantiation (11..64 columns, mixed segments)
+    u64* heavy_flag;                        // per variant segment: on the heavy list (scanned into the list position)
+    u64* heavy2_vi; u64* heavy2_cm; u64* heavy2_n;   // what the light instantiation gives up on (another alphabet): second heavy pass
     uint8_t* eds; uint8_t* seds; u64 tok_total;
     uint8_t* rec; u32 rec_stride, rec_gid;  // grouping records (count -> emit): stride, bytes of the group-id area
     const u64* Fraw; const u32* rec_info;   // column scan's own groupings: first-column bitmap, k | textlen << 8 | ok << 31 per slot
     const uint8_t* recf; u32 recf_stride, recf_gid;   // ... and their records (indexed by slot)
+    u64* long_list; u64* long_count;        // common segments for k_emit_common_long
 };
 
 class MsaPipeline {
@@ -174,7 +179,8 @@ private:
     std::vector<TimedKernel> timed_;
 
     DevBuf hdr_, rows_, vraw_, v_, wslot_, vc_, hrun_, hseg_, cnt_, wbase_, segbase_, scan_tmp_,
-           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, cnt_list_, rec_, recf_, rec_info_, fraw_, colbuf_, idx_tmp_, gcache_;
+           run_start_, flag_, seg_start_, eds_len_, seds_len_, segmeta_, slow_list_, cnt_list_, rec_, recf_, rec_info_, fraw_, colbuf_, idx_tmp_, gcache_,
+           long_list_;
     u64 vc_cap_cols_ = 0;
 
     // emit-time view

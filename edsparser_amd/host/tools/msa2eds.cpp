@@ -20,6 +20,7 @@ int main(int argc, char** argv)
         opts.add("output", 'o', true, false, "Output EDS file (default: <input>.eds)");
         opts.add("sources", 's', true, false, "Output source file (default: <output>.seds)");
         opts.add("context-length", 'l', true, false, "Create l-EDS with minimum context length (0 = regular EDS)");
+        opts.add("gpus", 'g', true, false, "Spread the alignment's columns over this many GPUs of the node (RCCL boundary stitch; default 1)");
         opts.parse(argc, argv);
         if (opts.has("help")) {
             std::cout << "msa2eds - Transform MSA (Multiple Sequence Alignment) to EDS\n\n" << opts.usage() << "\n"
@@ -30,7 +31,8 @@ int main(int argc, char** argv)
                          "EXAMPLES:\n"
                          "  msa2eds -i alignment.msa            # alignment.eds + alignment.seds\n"
                          "  msa2eds -i alignment.msa -l 10      # alignment_l10.leds + alignment_l10.seds\n"
-                         "  msa2eds -i alignment.msa -o output.eds -s output.seds\n\n"
+                         "  msa2eds -i alignment.msa -o output.eds -s output.seds\n"
+                         "  msa2eds -i alignment.msa --gpus 8   # column slabs on GPUs 0..7, stitched over RCCL\n\n"
                          "IMPLEMENTATION:\n"
                          "  The alignment is transformed on an AMD MI355X (gfx950) through libedsx.\n\n";
             tool::print_performance(timer);
@@ -57,10 +59,29 @@ int main(int argc, char** argv)
         else std::cout << "MSA → EDS transformation\n";
         std::cout << "  Input: " << input_file << "\n";
 
-        edsx_ctx* ctx = detail::context();
         detail::Buf eds_out, seds_out;
-        const int rc = edsx_msa_transform(ctx, msa_in.data(), msa_in.size(), context_length, &eds_out.b, &seds_out.b);
-        if (rc != EDSX_OK) detail::throw_status(rc, ctx);
+        if (opts.has("gpus")) {
+            // N rank threads inside the library, one per GPU (devices 0 .. N-1), ncclAllGather for the boundary stitch
+            const unsigned long ngpu = opts.get_unsigned("gpus", 1);
+            if (ngpu == 0 || ngpu > 64) throw std::runtime_error("--gpus must be between 1 and 64");
+            std::vector<int> devs(ngpu);
+            for (unsigned long i = 0; i < ngpu; i++) devs[i] = static_cast<int>(i);
+            edsx_multi* mg = nullptr;
+            if (edsx_multi_create(devs.data(), static_cast<int>(ngpu), 1, &mg) != EDSX_OK)
+                throw std::runtime_error("cannot use " + std::to_string(ngpu) + " GPUs (gfx950 devices 0.." + std::to_string(ngpu - 1) + " with RCCL)");
+            const int rc = edsx_msa_transform_multi(mg, msa_in.data(), msa_in.size(), context_length, &eds_out.b, &seds_out.b);
+            const std::string what = rc != EDSX_OK ? edsx_multi_last_error(mg) : "";
+            int parted = 0, chains = 0;
+            edsx_multi_last_partition(mg, &parted, &chains);
+            edsx_multi_destroy(mg);
+            if (rc != EDSX_OK) throw std::runtime_error(what);
+            std::cout << "  GPUs: " << ngpu << (parted ? " (column slabs, " + std::to_string(chains) + " boundary segments stitched)"
+                                                         : std::string(ngpu > 1 ? " (not partitioned: one GPU transforms the file)" : "")) << "\n";
+        } else {
+            edsx_ctx* ctx = detail::context();
+            const int rc = edsx_msa_transform(ctx, msa_in.data(), msa_in.size(), context_length, &eds_out.b, &seds_out.b);
+            if (rc != EDSX_OK) detail::throw_status(rc, ctx);
+        }
 
         std::filesystem::path eds_path, seds_path;
         if (create_leds) {

@@ -62,7 +62,7 @@ struct MemoryModel {
     {
         const uint64_t payload = N + 32 * m + 24 * n;            // characters + std::string headers + vector headers
         full = payload + payload / 5;                            // + 20 % allocator bookkeeping
-        const uint64_t index = (8 + 4 + 4 + 1) * n + 4 * n + 4 * m + 64;   // per-symbol tables, per-string lengths, fixed part
+        const uint64_t index = (8 + 4 + 4 + 1) * n + 4 * m + 64;           // per-symbol tables, per-string lengths, fixed part
         metadata = index + index / 10;
     }
     double reduction() const { return static_cast<double>(full) / static_cast<double>(metadata); }

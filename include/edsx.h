@@ -187,6 +187,23 @@ int edsx_msa_copy_columns(edsx_ctx* ctx, uint64_t col0, uint64_t ncols, uint8_t*
 int edsx_msa_locate_segment(edsx_ctx* ctx, uint64_t col, uint64_t* seg, uint64_t* seg_col, uint64_t* eds_off,
                             uint64_t* seds_off);
 
+/* ---- MSA -> EDS over several GPUs of one node, from C/C++ (replaces the single call of msa2eds.cpp:123-132 when the
+ * alignment should be spread over N GPUs) ----
+ * One host thread per GPU inside the call.  The alignment columns are range-partitioned into n column slabs; every
+ * GPU transforms its slab, and the segments that cross a slab boundary are stitched with KB-sized all-gathers:
+ * ncclAllGather over RCCL (use_rccl = 1: one distinct device per rank), or an in-process exchange between the rank
+ * threads (use_rccl = 0: ranks may share a device - rehearsals and tests on a one-GPU box).  Output is byte-identical
+ * to edsx_msa_transform.  context_len > 0 and files that are not plain uniform alignments are transformed by rank 0
+ * alone. */
+typedef struct edsx_multi edsx_multi;
+int  edsx_multi_create(const int* device_ids, int n, int use_rccl, edsx_multi** out);
+void edsx_multi_destroy(edsx_multi* m);
+const char* edsx_multi_last_error(const edsx_multi* m);
+int  edsx_msa_transform_multi(edsx_multi* m, const uint8_t* msa, size_t msa_size, uint32_t context_len,
+                              edsx_buf* eds, edsx_buf* seds);
+/* of the last edsx_msa_transform_multi: 1 if the columns were partitioned, the number of boundary chains stitched */
+int  edsx_multi_last_partition(const edsx_multi* m, int* partitioned, int* chains);
+
 /* Per-kernel device time, measured with HIP events on the stream each kernel is launched on and
  * accumulated over all plan/emit calls since edsx_set_timing(ctx, 1).  Arrays of capacity cap;
  * total_ms[i] / launches[i] is the average duration of kernel names[i].  Returns the entry count. */
