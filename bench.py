@@ -31,6 +31,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["c5", "c2"], default="c5",
+                    help="c5: BASELINE configs[4], 1000 sequences x 100 Mb (the headline, default); c2: BASELINE configs[1], "
+                         "64 sequences x 10 Mb (a parity-test shape; its line is kept on record under profiles/)")
     ap.add_argument("--rows", type=int, default=1000)
     ap.add_argument("--cols", type=int, default=100_000_000,
                     help="alignment columns (strong scaling: of the whole alignment; weak: per GPU)")
@@ -49,9 +52,20 @@ def parse_args():
                     help="N=1, context length 0: after the timed region compare sampled column windows of the outputs "
                          "(spread over the whole width, incl. offsets beyond 4 GiB and the last columns) with the CPU "
                          "oracle (tests/fullsize_verify.py); 0 = skip")
+    ap.add_argument("--row-align", type=int, default=0,
+                    help="lay the synthetic rows out with blank-padded headers so that every row starts on a multiple of "
+                         "this many bytes (0: the plain FASTA image - the headline workload)")
+    ap.add_argument("--aligned-probe", type=int, default=128,
+                    help="N=1: after the timed run repeat it on the same alignment laid out with rows on multiples of this many "
+                         "bytes (what an upload that places the rows for the scan produces) and report it beside the headline "
+                         "under \"aligned_rows\"; 0 = skip")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload == "c2":
+        a.rows, a.cols = 64, 10_000_000
+        a.cpu_baseline_mb = min(a.cpu_baseline_mb, 640.0)
+    return a
 
 
 def cpu_baseline(ctx, torch, rows, sample_mb, vfrac, seed, l):
@@ -79,6 +93,8 @@ def cpu_baseline(ctx, torch, rows, sample_mb, vfrac, seed, l):
     except OSError:
         pass
     return {"value": round(n / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port", "cpu_model": model,
+            "flavour": "oracle/msa_oracle.cpp on an in-memory image of the file (the reference's three passes without its "
+                       "seek-per-sequence file reads: the faster of the two flavours BASELINE.md names)",
             "host_cores": os.cpu_count(),
             "sample": "%d rows x %d columns (%.0f MB in, %.1f s), same generator and site fraction"
                       % (rows, cols, n / 1e6, dt)}
@@ -115,10 +131,10 @@ def main():
     else:
         col0, col1 = a.cols * rank, a.cols * (rank + 1)
     L = col1 - col0
-    n = edsparser_amd.synth_size(S, L)
+    n = edsparser_amd.synth_size(S, L, a.row_align)
     msa = torch.empty(n, dtype=torch.uint8, device="cuda")
     ctx.msa_synth_device(msa.data_ptr(), n, S, L, col0=col0, variant_fraction=a.variant_fraction,
-                         seed=a.seed)
+                         seed=a.seed, row_align=a.row_align)
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -200,7 +216,11 @@ def main():
             ach = alg / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4),
+                    "traffic": traffic,
+                    "traffic_source": ("--traffic-bytes" if a.traffic_bytes is not None else
+                                       "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build "
+                                       "(profiles/collect.sh), not counted in this run") if traffic is not None else None,
+                    "avg_kernel_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": alg, "algorithmic_bytes": what}
         verify = None
         if world == 1 and a.verify and l == 0:
@@ -208,6 +228,42 @@ def main():
             from fullsize_verify import verify_windows
             verify = verify_windows(ctx, torch, S, L, a.seed, a.variant_fraction, out["eds"], out["seds"],
                                     out["E"], out["Q"])
+        aligned = None
+        if world == 1 and a.aligned_probe > 1 and a.row_align != a.aligned_probe:
+            # The same cells with every row on a multiple of --aligned-probe bytes (blank-padded headers).  The scan's 16-byte
+            # loads are then aligned; a FASTA image as it comes (the headline above) has every row at its own odd offset.
+            first = (out["eds"][:out["E"]].clone(), out["seds"][:out["Q"]].clone(), out["E"], out["Q"])
+            del msa
+            torch.cuda.empty_cache()
+            n2 = edsparser_amd.synth_size(S, L, a.aligned_probe)
+            msa2 = torch.empty(n2, dtype=torch.uint8, device="cuda")
+            ctx.msa_synth_device(msa2.data_ptr(), n2, S, L, col0=col0, variant_fraction=a.variant_fraction, seed=a.seed,
+                                 row_align=a.aligned_probe)
+            torch.cuda.synchronize()
+
+            def step2():
+                E, Q = ctx.msa_plan_device(msa2.data_ptr(), n2, l, stream)
+                ctx.msa_emit_device(out["eds"].data_ptr(), out["seds"].data_ptr(), stream)
+                return E, Q
+            step2()
+            torch.cuda.synchronize()
+            ctx.set_timing(True)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                E2, Q2 = step2()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            tm2 = {nm: tot / max(cnt, 1) for nm, tot, cnt in ctx.get_timing()}
+            ctx.set_timing(False)
+            same = (E2, Q2) == (first[2], first[3]) and bool(torch.equal(out["eds"][:E2], first[0])) and \
+                bool(torch.equal(out["seds"][:Q2], first[1]))
+            v2 = n2 * a.steps / dt2 / 1e6
+            aligned = {"row_align": a.aligned_probe, "input_bytes": n2, "ms_per_step": round(dt2 / a.steps * 1e3, 3),
+                       "value": round(v2, 1), "unit": "MB/s",
+                       "frac_of_hbm_read_roofline": round(v2 * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
+                       "k_scan_extract_ms": round(tm2.get("k_scan_extract", 0.0), 4),
+                       "outputs_equal_headline_run": same}
+            del msa2, first
         cpu = None
         if world == 1 and a.cpu_baseline_mb > 0:
             cpu = cpu_baseline(ctx, torch, S, a.cpu_baseline_mb, a.variant_fraction, a.seed, l)
@@ -229,7 +285,7 @@ def main():
                        "partition": "columns x %d" % world,
                        "stitch": (out.get("stitch") or {}).get("chains") if distributed else None},
             "frac_of_hbm_read_roofline": round(value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4),
-            "roofline": roof, "cpu_baseline": cpu, "verify": verify, "kernel_ms": per_kernel,
+            "roofline": roof, "cpu_baseline": cpu, "verify": verify, "aligned_rows": aligned, "kernel_ms": per_kernel,
         }
         print(json.dumps(line), flush=True)
     if distributed:

@@ -114,6 +114,12 @@ def load_library():
     lib.edsx_multi_last_error.restype = ctypes.c_char_p
     lib.edsx_msa_transform_multi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, P(_Buf), P(_Buf)]
     lib.edsx_multi_last_partition.argtypes = [ctypes.c_void_p, P(ctypes.c_int), P(ctypes.c_int)]
+    lib.edsx_genvcf.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, P(_Buf), P(_Buf)]
+    lib.edsx_msa_synth_size_aligned.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32]
+    lib.edsx_msa_synth_size_aligned.restype = ctypes.c_size_t
+    lib.edsx_msa_synth_device_aligned.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                                  ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double, ctypes.c_uint64,
+                                                  ctypes.c_uint32, ctypes.c_void_p, P(ctypes.c_size_t)]
     _LIB = lib
     return lib
 
@@ -165,7 +171,9 @@ class MultiGpu:
         return bool(p.value), int(c.value)
 
 
-def synth_size(n_rows, n_cols):
+def synth_size(n_rows, n_cols, row_align=0):
+    if row_align > 1:
+        return int(load_library().edsx_msa_synth_size_aligned(n_rows, n_cols, row_align))
     return int(load_library().edsx_msa_synth_size(n_rows, n_cols))
 
 
@@ -339,9 +347,19 @@ class Context:
         n = self._lib.edsx_get_timing(self._h, names, ms, cnt, cap)
         return [(names[i].decode(), float(ms[i]), int(cnt[i])) for i in range(n)]
 
+    def genvcf(self, ref_len, n_records, n_samples=8, seed=42):
+        """Synthetic (vcf, fasta) bytes of BASELINE configs[3]'s shape, generated on the device."""
+        v, f = _Buf(), _Buf()
+        self._check(self._lib.edsx_genvcf(self._h, ref_len, n_records, n_samples, seed, ctypes.byref(v), ctypes.byref(f)))
+        return self._take(v), self._take(f)
+
     def msa_synth_device(self, d_out, capacity, n_rows, n_cols, col0=0, variant_fraction=0.05, seed=42,
-                         stream=0):
+                         stream=0, row_align=0):
         w = ctypes.c_size_t()
-        self._check(self._lib.edsx_msa_synth_device(self._h, d_out, capacity, n_rows, col0, n_cols,
-                                                    variant_fraction, seed, stream, ctypes.byref(w)))
+        if row_align > 1:
+            self._check(self._lib.edsx_msa_synth_device_aligned(self._h, d_out, capacity, n_rows, col0, n_cols,
+                                                                variant_fraction, seed, row_align, stream, ctypes.byref(w)))
+        else:
+            self._check(self._lib.edsx_msa_synth_device(self._h, d_out, capacity, n_rows, col0, n_cols,
+                                                        variant_fraction, seed, stream, ctypes.byref(w)))
         return int(w.value)

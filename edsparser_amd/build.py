@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libedsx.so")
-SOURCES = ["msa_device.hip", "merge_device.hip", "vcf_device.hip", "synth.hip", "genrandom.hip", "multi_gpu.hip", "capi.hip"]
+SOURCES = ["msa_device.hip", "merge_device.hip", "vcf_device.hip", "synth.hip", "genrandom.hip", "genvcf.hip", "multi_gpu.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

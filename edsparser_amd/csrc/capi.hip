@@ -2,6 +2,7 @@
 #include "../../include/edsx.h"
 
 #include "genrandom.hpp"
+#include "genvcf.hpp"
 #include "merge_device.hpp"
 #include "msa_device.hpp"
 #include "multi_gpu.hpp"
@@ -24,7 +25,9 @@ struct edsx_ctx {
     MergePipeline merge;
     VcfPipeline vcf;
     GenPipeline gen;
+    GenVcfPipeline genvcf;
     DevBuf d_in, d_eds, d_seds, synth_desc;
+    std::vector<uint8_t> host_tmp;
 };
 
 namespace {
@@ -213,10 +216,20 @@ int edsx_msa_transform(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint3
         if (!msa || !eds || !seds) throw ParamError("null argument");
         if (msa_size == 0) throw FormatError("Invalid MSA: empty input");
         hipStream_t st = nullptr;
-        ctx->d_in.ensure(msa_size);
-        EDSX_HIP(hipMemcpyAsync(ctx->d_in.ptr, msa, msa_size, hipMemcpyHostToDevice, st));
+        // A plain uniform alignment of some size goes to HBM as a row image whose rows all begin on multiples of 128
+        // bytes (2D copies: free on the way up): the column scan's loads are then aligned (multi_gpu.hip).  Everything
+        // else - small inputs, files the geometry walk does not accept - is copied as it is, and the transform itself
+        // words what is wrong with it.
+        MsaLayout lay;
+        if (msa_size >= ((size_t)1 << 20)) lay = msa_layout(msa, msa_size);
+        size_t dev_size = msa_size;
+        if (lay.ok) dev_size = (size_t)upload_row_image(msa, lay, 0, lay.L, ctx->d_in, ctx->host_tmp, st).bytes;
+        else {
+            ctx->d_in.ensure(msa_size);
+            EDSX_HIP(hipMemcpyAsync(ctx->d_in.ptr, msa, msa_size, hipMemcpyHostToDevice, st));
+        }
         uint64_t E = 0, Q = 0;
-        ctx->msa.plan(ctx->d_in.as<uint8_t>(), msa_size, context_len, st, &E, &Q);
+        ctx->msa.plan(ctx->d_in.as<uint8_t>(), dev_size, context_len, st, &E, &Q);
         ctx->d_eds.ensure(E + 16);
         ctx->d_seds.ensure(Q + 16);
         ctx->msa.emit(ctx->d_eds.as<uint8_t>(), ctx->d_seds.as<uint8_t>(), st);
@@ -412,6 +425,19 @@ int edsx_genrandomeds(edsx_ctx* ctx, uint64_t total_bp, double variability, uint
     });
 }
 
+int edsx_genvcf(edsx_ctx* ctx, uint64_t ref_len, uint64_t n_records, uint32_t n_samples, uint64_t seed, edsx_buf* vcf, edsx_buf* fasta)
+{
+    if (vcf) { vcf->data = nullptr; vcf->size = 0; }
+    if (fasta) { fasta->data = nullptr; fasta->size = 0; }
+    return guarded(ctx, [&] {
+        if (!vcf || !fasta) throw ParamError("null argument");
+        HostBytes v, f;
+        ctx->genvcf.run(ref_len, n_records, n_samples, seed, v, f, nullptr);
+        vcf->size = v.size; vcf->data = v.release();
+        fasta->size = f.size; fasta->data = f.release();
+    });
+}
+
 size_t edsx_msa_synth_size(uint32_t n_rows, uint64_t n_cols) { return synth_size(n_rows, n_cols); }
 
 int edsx_msa_synth_device(edsx_ctx* ctx, uint8_t* d_out, size_t capacity, uint32_t n_rows,
@@ -425,6 +451,24 @@ int edsx_msa_synth_device(edsx_ctx* ctx, uint8_t* d_out, size_t capacity, uint32
         ctx->synth_desc.ensure(8 * (size_t)n_cols);
         synth_generate(d_out, ctx->synth_desc.as<u64>(), n_rows, col0, n_cols, variant_fraction, seed,
                        static_cast<hipStream_t>(stream));
+        EDSX_HIP(hipGetLastError());
+        if (written) *written = need;
+    });
+}
+
+size_t edsx_msa_synth_size_aligned(uint32_t n_rows, uint64_t n_cols, uint32_t row_align) { return synth_size_aligned(n_rows, n_cols, row_align); }
+
+int edsx_msa_synth_device_aligned(edsx_ctx* ctx, uint8_t* d_out, size_t capacity, uint32_t n_rows, uint64_t col0, uint64_t n_cols,
+                                  double variant_fraction, uint64_t seed, uint32_t row_align, void* stream, size_t* written)
+{
+    return guarded(ctx, [&] {
+        if (!d_out || n_rows < 1 || n_cols < 1 || n_rows > 99999) throw ParamError("bad synthetic alignment geometry");
+        if (row_align > 1 && (row_align & (row_align - 1))) throw ParamError("row alignment must be a power of two");
+        size_t need = synth_size_aligned(n_rows, n_cols, row_align);
+        if (capacity < need) throw ParamError("output buffer too small for the synthetic alignment");
+        ctx->synth_desc.ensure(8 * (size_t)n_cols);
+        synth_generate(d_out, ctx->synth_desc.as<u64>(), n_rows, col0, n_cols, variant_fraction, seed,
+                       static_cast<hipStream_t>(stream), row_align);
         EDSX_HIP(hipGetLastError());
         if (written) *written = need;
     });

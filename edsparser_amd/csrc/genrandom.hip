@@ -146,13 +146,13 @@ __global__ void __launch_bounds__(256) k_gen(GenDev g, u64* __restrict__ eb, u64
 void GenPipeline::run(const GenParams& p, HostBytes& eds, HostBytes& seds, u64& n_sites, hipStream_t st)
 {
     if (p.total_bp == 0) throw ParamError("Reference size must be greater than 0");
-    if (p.variability < 0.0 || p.variability > 1.0) throw ParamError("Variability must be between 0.0 and 1.0");
+    if (!(p.variability >= 0.0 && p.variability <= 1.0)) throw ParamError("Variability must be between 0.0 and 1.0");   // (NaN fails too)
     if (p.min_alt < 2) throw ParamError("Minimum alternatives must be at least 2");
     if (p.max_alt < p.min_alt) throw ParamError("Maximum alternatives must be >= minimum alternatives");
     if (p.max_alt > 16) throw ParamError("Maximum alternatives above 16 are not supported by this build");
     if (p.var_len_max == 0) throw ParamError("Variant length max must be greater than 0");
     if (p.var_len_max > 63) throw ParamError("Variant length max above 63 is not supported by this build");
-    if (p.snp_ratio < 0.0 || p.snp_ratio > 1.0) throw ParamError("SNP ratio must be between 0.0 and 1.0");
+    if (!(p.snp_ratio >= 0.0 && p.snp_ratio <= 1.0)) throw ParamError("SNP ratio must be between 0.0 and 1.0");
     if (p.alpha_n == 0 || p.alpha_n > 64) throw ParamError("Alphabet cannot be empty");
     GenDev g{};
     g.total_bp = p.total_bp; g.thr = (u64)(p.variability * 1099511627776.0); g.min_context = p.min_context; g.seed = p.seed;

@@ -289,7 +289,8 @@ struct K1Params {
     // grouped right here, from the LDS image of the tile's variant columns; only the other columns go to vc
     u32 fuse; u64* Fraw; u32* rec_info; uint8_t* recf; u32 recf_stride, recf_gid;
 };
-constexpr u32 FUSE_MAXW = 10;      // widest run grouped by the column scan (exact 3-bit-per-column keys in one dword)
+constexpr u32 FUSE_MAXW = 10;      // widest run grouped by the column scan (exact 3-bit-per-column keys in one dword; two-dword keys
+                                   // for 11..20 columns spill 71 registers here - rounds 2 and 3)
 #ifndef EDSX_TAIL_WAVES
 #define EDSX_TAIL_WAVES 8
 #endif
@@ -803,6 +804,10 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     uint4 ref = make_uint4(0, 0, 0, 0);
     uint4 d[HOLD ? RPT : 1];
     uint4 acc = make_uint4(0, 0, 0, 0);                        // OR over rows of (row ^ ref): a byte is
+    // (Rows of a FASTA image sit at odd byte offsets, and 16-byte lane loads from addresses that are not multiples of 4
+    // stream a quarter slower than dword-aligned ones - profiles/exp/scan_skel4.  Loading from the address rounded down
+    // to a multiple of 4 and shifting the bytes into place with v_alignbyte_b32 + DPP was built and measured in round 3:
+    // the ~180 extra instructions per thread sit exactly where the workgroup is issue-bound, 30.9 instead of 26.8 ms.)
     if (direct) {
         if constexpr (DIRECT_OK) {
             ref = load16u(f + p.row_start[0] + q);
@@ -881,8 +886,11 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     u64 prepk = 0;                                             // byte c: variant columns in chunks 0 .. c-1
     u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0, nv = 0;
     if (fastpre) {
+        // (the masks are the same in every lane: as scalars their popcounts and the packing run on the scalar unit,
+        // beside the vector work of the SIMD's other waves)
         const uint4 da = *reinterpret_cast<const uint4*>(&D[0]), db = *reinterpret_cast<const uint4*>(&D[4]);
-        const u32 dm[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+        const u32 dm[8] = {uniform32(da.x), uniform32(da.y), uniform32(da.z), uniform32(da.w),
+                           uniform32(db.x), uniform32(db.y), uniform32(db.z), uniform32(db.w)};
 #pragma unroll
         for (int c = 0; c < 8; c++) { prepk |= (u64)nv << (8 * c); nv += (u32)__builtin_popcount(dm[c]); }
     } else {
@@ -2132,6 +2140,8 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
     }
     if constexpr (HEAVY) {
         if (ncol > 10u && ncol <= 20u && !mixed) {         // 11..20 columns over the DNA alphabet: exact keys in two dwords
+            // (fetching the columns into LDS by LDS-DMA in one round trip - no registers for more than four loads in flight -
+            // was built and measured in round 3: 1.33 vs 1.35 ms, the kernel is bound by its instructions, not by the loads)
             auto load_col = [&](u32 c) -> uint4 { return load16u(col_ptr(c)); };
             const int r = fast_group_dnakeys<2>(load_col, ncol, col0, lane, vmask, G);
             if (r) return r > 0 ? 1 : 0;
@@ -3198,7 +3208,9 @@ void MsaPipeline::plan_body(hipStream_t st)
 
     // grouping cache of the generic kernels (count -> emit): two regions (one per work list; without lists: both)
     gc_stride_ = gcache_stride_of((u32)S);
-    gc_region_ = (size_t)std::min<u64>((u64)1 << 30, (L / 2 + 4) * (u64)gc_stride_);
+    // (with the wave-per-segment kernels in front - up to 1024 rows - only the few segments on their slow lists come here:
+    // 256 MiB per list; items beyond the cache are simply grouped again by the emitter)
+    gc_region_ = (size_t)std::min<u64>((u64)(S <= 1024 ? 256u : 1024u) << 20, (L / 2 + 4) * (u64)gc_stride_);
     gc_region_ = gc_region_ / gc_stride_ * gc_stride_;
     gcache_.ensure(2 * gc_region_ + 16);
 

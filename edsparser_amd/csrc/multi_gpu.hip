@@ -184,17 +184,72 @@ private:
     std::vector<DevBuf> send_, recv_;
 };
 
-// ">r\n" in front of every row of a slab image and '\n' behind it (the data comes by 2D copies)
-__global__ void k_slab_frame(uint8_t* __restrict__ img, u64 nrows, u64 ncols)
+// header of every row of a row image: ">r", blanks, newline; and the newline behind the row's columns
+__global__ void k_row_frames(uint8_t* __restrict__ img, u64 nrows, u64 ncols, u64 h0, u64 h)
 {
-    const u64 pitch = ncols + 4;
-    for (u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x; r < nrows; r += (u64)gridDim.x * blockDim.x) {
-        uint8_t* p = img + r * pitch;
-        p[0] = '>'; p[1] = 'r'; p[2] = '\n'; p[3 + ncols] = '\n';
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u32 lane = threadIdx.x & 63;
+    for (u64 r = wave; r < nrows; r += nwaves) {
+        const u64 hl = r ? h : h0;
+        uint8_t* p = img + (r ? h0 + (ncols + 1) + (r - 1) * (h + ncols + 1) : 0);
+        for (u64 i = lane; i < hl; i += 64) p[i] = i == 0 ? '>' : i == 1 ? 'r' : i + 1 == hl ? '\n' : ' ';
+        if (lane == 0) p[hl + ncols] = '\n';
     }
 }
 
 } // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row image: columns [c0, c1) of every row of a host FASTA image as a one-line-per-row image in HBM whose rows all begin
+// on multiples of 128 bytes (blank-padded headers).  The column scan reads every row in 128-byte pieces; from a
+// 128-byte-aligned row those loads are aligned, and the scan of the 1000 x 100 Mb alignment takes 21.8 instead of
+// 26.9 ms (round 3, bench.py "aligned_rows").  A row's slab is one contiguous piece of the file (one-line rows), so
+// the upload is a 2D copy per stretch of equally spaced rows; wrapped rows are put together on the host.
+// ---------------------------------------------------------------------------------------------------------------
+RowImage upload_row_image(const uint8_t* fasta, const MsaLayout& lay, u64 c0, u64 c1, DevBuf& d_img, std::vector<uint8_t>& host_tmp,
+                          hipStream_t st)
+{
+    RowImage ri;
+    const u64 S = lay.start.size(), ncols = c1 - c0;
+    ri.rows = S; ri.cols = ncols;
+    ri.hdr0 = 128;
+    ri.hdr = (128 - (ncols + 1) % 128) % 128;
+    if (ri.hdr < 8) ri.hdr += 128;
+    ri.bytes = ri.hdr0 + S * (ncols + 1) + (S - 1) * ri.hdr;
+    d_img.ensure(ri.bytes + 16);
+    uint8_t* img = d_img.as<uint8_t>();
+    const u64 pitch = ri.hdr + ncols + 1;                      // rows 1 .. S-1
+    auto data_off = [&](u64 r) { return r ? ri.hdr0 + (ncols + 1) + (r - 1) * pitch + ri.hdr : ri.hdr0; };
+    if (lay.lw == 0) {
+        // rows with headers of equal length are equally spaced in the file: one 2D copy per such stretch of rows
+        EDSX_HIP(hipMemcpyAsync(img + data_off(0), fasta + lay.start[0] + c0, ncols, hipMemcpyHostToDevice, st));
+        for (u64 s0 = 1; s0 < S;) {
+            u64 s1 = s0;                                       // last row of the stretch
+            const u64 sp = s0 + 1 < S ? lay.start[s0 + 1] - lay.start[s0] : pitch;
+            while (s1 + 1 < S && lay.start[s1 + 1] - lay.start[s1] == sp) s1++;
+            const u64 nrows = s1 - s0 + 1;
+            EDSX_HIP(hipMemcpy2DAsync(img + data_off(s0), pitch, fasta + lay.start[s0] + c0, sp, ncols, nrows, hipMemcpyHostToDevice, st));
+            s0 += nrows;
+        }
+    } else {
+        // wrapped rows: columns [c0, c1) of a row are the bytes c + c / lw without the newlines between them
+        host_tmp.resize(S * ncols);
+        for (u64 s = 0; s < S; s++) {
+            uint8_t* d = host_tmp.data() + s * ncols;
+            const uint8_t* row = fasta + lay.start[s];
+            for (u64 c = c0; c < c1;) {
+                const u64 in_line = c % lay.lw, take = std::min<u64>(lay.lw - in_line, c1 - c);
+                std::memcpy(d, row + c + c / lay.lw, take);
+                d += take; c += take;
+            }
+        }
+        EDSX_HIP(hipMemcpyAsync(img + data_off(0), host_tmp.data(), ncols, hipMemcpyHostToDevice, st));
+        if (S > 1) EDSX_HIP(hipMemcpy2DAsync(img + data_off(1), pitch, host_tmp.data() + ncols, ncols, ncols, S - 1, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_row_frames, dim3(64), dim3(256), 0, st, img, S, ncols, ri.hdr0, ri.hdr);
+    EDSX_HIP(hipGetLastError());
+    return ri;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // MultiMsa
@@ -282,7 +337,6 @@ void MultiMsa::run_rank(int r, const uint8_t* fasta, size_t n, const MsaLayout& 
     };
     const u64 S = lay.start.size(), L = lay.L;
     const u64 c0 = L * (u64)r / (u64)N, c1 = L * (u64)(r + 1) / (u64)N, ncols = c1 - c0;
-    const u64 pitch = ncols + 4, img_bytes = S * pitch;
     hipStream_t st = nullptr;
     uint64_t E = 0, Q = 0;
     SlabEdges mine{};
@@ -291,35 +345,9 @@ void MultiMsa::run_rank(int r, const uint8_t* fasta, size_t n, const MsaLayout& 
     // ---- 1. slab image -> HBM, plan, emit, edge descriptors
     if (!phase([&] {
             EDSX_HIP(hipSetDevice(me.device));
-            me.d_img.ensure(img_bytes + 16);
-            uint8_t* img = me.d_img.as<uint8_t>();
-            if (lay.lw == 0) {
-                // rows with headers of equal length are equally spaced in the file: one 2D copy per such stretch of rows
-                for (u64 s0 = 0; s0 < S;) {
-                    u64 s1 = s0 + 1;
-                    const u64 sp = s1 < S ? lay.start[s1] - lay.start[s0] : pitch;
-                    while (s1 + 1 < S && lay.start[s1 + 1] - lay.start[s1] == sp) s1++;
-                    if (s1 < S && s1 == s0 + 1 && S > 1) { /* a stretch of one or two rows: still one copy */ }
-                    const u64 nrows = (s1 < S ? s1 : S - 1) - s0 + 1;
-                    EDSX_HIP(hipMemcpy2DAsync(img + s0 * pitch + 3, pitch, fasta + lay.start[s0] + c0, sp, ncols, nrows,
-                                               hipMemcpyHostToDevice, st));
-                    s0 += nrows;
-                }
-            } else {
-                // wrapped rows: columns [c0, c1) of a row are the bytes c + c / lw without the newlines between them
-                me.host_img.resize(img_bytes);
-                for (u64 s = 0; s < S; s++) {
-                    uint8_t* d = me.host_img.data() + s * pitch + 3;
-                    const uint8_t* row = fasta + lay.start[s];
-                    for (u64 c = c0; c < c1;) {
-                        const u64 in_line = c % lay.lw, take = std::min<u64>(lay.lw - in_line, c1 - c);
-                        std::memcpy(d, row + c + c / lay.lw, take);
-                        d += take; c += take;
-                    }
-                }
-                EDSX_HIP(hipMemcpyAsync(img, me.host_img.data(), img_bytes, hipMemcpyHostToDevice, st));
-            }
-            hipLaunchKernelGGL(k_slab_frame, dim3(64), dim3(256), 0, st, img, S, ncols);
+            const RowImage ri = upload_row_image(fasta, lay, c0, c1, me.d_img, me.host_img, st);
+            const uint8_t* img = me.d_img.as<uint8_t>();
+            const u64 img_bytes = ri.bytes;
             me.slab.plan(img, img_bytes, 0, st, &E, &Q);
             me.d_eds.ensure(E + 16); me.d_seds.ensure(Q + 16);
             me.slab.emit(me.d_eds.as<uint8_t>(), me.d_seds.as<uint8_t>(), st);

@@ -38,6 +38,11 @@ StitchPlan plan_stitch(const std::vector<SlabEdges>& edges);               // pu
 struct MsaLayout { bool ok = false; std::vector<u64> start; u64 draw = 0, lw = 0, L = 0; };
 MsaLayout msa_layout(const uint8_t* f, size_t n);
 
+// columns [c0, c1) of every row as a one-line-per-row image in HBM, every row on a multiple of 128 bytes (see multi_gpu.hip)
+struct RowImage { u64 rows = 0, cols = 0, hdr0 = 0, hdr = 0, bytes = 0; };
+RowImage upload_row_image(const uint8_t* fasta, const MsaLayout& lay, u64 c0, u64 c1, DevBuf& d_img, std::vector<uint8_t>& host_tmp,
+                          hipStream_t st);
+
 // all ranks call with `bytes` bytes each; `all` receives world * bytes bytes in rank order
 class Exchange {
 public:

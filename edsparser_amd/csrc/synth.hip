@@ -24,6 +24,22 @@ size_t synth_size(u32 S, u64 ncols)
     return (size_t)S * (ncols + 1 + 3) + cumdigits(S);
 }
 
+// Row-aligned variant: every header is padded with blanks so that the row's first column is a multiple of `align` bytes
+// from the image (what an upload that lays the rows out for the column scan produces; the FASTA stays valid).
+// Header bytes of row 0 / of every later row (incl. '>' and '\n'):
+__host__ __device__ static inline u64 aligned_hdr0(u64 align) { return align * ((8 + align - 1) / align); }
+__host__ __device__ static inline u64 aligned_hdr(u64 ncols, u64 align)
+{
+    u64 h = (align - (ncols + 1) % align) % align;
+    while (h < 8) h += align;                       // room for ">s<idx>" of up to five digits and the newline
+    return h;
+}
+size_t synth_size_aligned(u32 S, u64 ncols, u32 align)
+{
+    if (align <= 1) return synth_size(S, ncols);
+    return (size_t)(aligned_hdr0(align) + (u64)S * (ncols + 1) + (u64)(S - 1) * aligned_hdr(ncols, align));
+}
+
 __device__ __forceinline__ bool site_raw(u64 seed, u64 gc, u64 vthr) { return (hash3(seed, gc, 1) >> 40) < vthr; }
 
 struct SiteAlts { u32 k; u32 kind[4]; u32 m[4]; u32 base[4]; };   // kind: 0 ref, 1 SNP, 2 INS, 3 DEL
@@ -91,21 +107,28 @@ __global__ void k_synth_desc(u64* __restrict__ desc, u64 col0, u64 ncols, u64 se
 struct __attribute__((packed, aligned(1))) Pack16 { uint8_t b[16]; };
 
 __global__ void k_synth_fill(uint8_t* __restrict__ out, const u64* __restrict__ desc, u32 S, u64 col0,
-                             u64 ncols, u64 seed)
+                             u64 ncols, u64 seed, u32 align)
 {
     const u64 chunks = (ncols + 15) / 16;
     const u64 total = (u64)S * chunks;
     for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
         const u32 row = (u32)(t / chunks);
         const u64 ch = t % chunks;
-        const u64 rowbase = (u64)row * (ncols + 1 + 3) + cumdigits(row);     // offset of '>'
         const u32 nd = ndig_host(row);
-        uint8_t* data = out + rowbase + 2 + nd + 1;
+        u64 rowbase, hlen;                                                   // offset of '>', header bytes incl. the newline
+        if (align <= 1) { rowbase = (u64)row * (ncols + 1 + 3) + cumdigits(row); hlen = 2 + nd + 1; }
+        else {
+            const u64 h0 = aligned_hdr0(align), h = aligned_hdr(ncols, align);
+            rowbase = row ? h0 + (ncols + 1) + (u64)(row - 1) * (h + ncols + 1) : 0;
+            hlen = row ? h : h0;
+        }
+        uint8_t* data = out + rowbase + hlen;
         if (ch == 0) {
             out[rowbase] = '>'; out[rowbase + 1] = 's';
             u32 v = row;
             for (int i = (int)nd - 1; i >= 0; i--) { out[rowbase + 2 + i] = (uint8_t)('0' + v % 10); v /= 10; }
-            out[rowbase + 2 + nd] = '\n';
+            for (u64 i = 2 + nd; i + 1 < hlen; i++) out[rowbase + i] = ' ';
+            out[rowbase + hlen - 1] = '\n';
             data[ncols] = '\n';
         }
         Pack16 pk;
@@ -126,11 +149,11 @@ __global__ void k_synth_fill(uint8_t* __restrict__ out, const u64* __restrict__ 
     }
 }
 
-void synth_generate(uint8_t* d_out, u64* d_desc, u32 S, u64 col0, u64 ncols, double v, u64 seed, hipStream_t st)
+void synth_generate(uint8_t* d_out, u64* d_desc, u32 S, u64 col0, u64 ncols, double v, u64 seed, hipStream_t st, u32 align)
 {
     u64 vthr = (u64)(v * 16777216.0);
     hipLaunchKernelGGL(k_synth_desc, dim3(4096), dim3(256), 0, st, d_desc, col0, ncols, seed, vthr);
-    hipLaunchKernelGGL(k_synth_fill, dim3(8192), dim3(256), 0, st, d_out, d_desc, S, col0, ncols, seed);
+    hipLaunchKernelGGL(k_synth_fill, dim3(8192), dim3(256), 0, st, d_out, d_desc, S, col0, ncols, seed, align);
 }
 
 } // namespace edsx

@@ -439,15 +439,32 @@ __global__ void k_tail(VcfDev d, u64 cur, u64 clen, uint8_t* eo, uint8_t* so)
 // that are "." or all digits (<= 9), no '\r'.  Anything else — the whitespace-separated fallback of :262-279,
 // malformed lines, unsupported structural variants (their warnings are in file order), signs or junk that
 // std::stoull/stoi would swallow, POS 0 — raises `bad`, and the host tokeniser takes the whole file.
-struct VtCtl { u64 n, bad, nrec, max_samples, t_alt, t_altc, t_pair, t_all; };
+struct VtCtl { u64 n, bad, nrec, max_samples, t_alt, t_altc, t_pair, t_all, oob; };
 
 struct VtSink {                      // fill pass: where record j's pieces go
     u64* altoff; u64 altc_base; uint8_t* altchars; u64* pa0; u64 all_base; int* alleles;
 };
 struct VtCounts { u64 pos; u64 reflen, nalt, altc, ngt, nall; };
 
+// The bytes of the VCF text through 8-byte aligned loads.  A thread walks its line from left to right, so seven of
+// eight byte reads come out of the register window instead of a one-byte load each (k_vt_count 0.80 -> 0.65 ms,
+// k_vt_fill 0.96 -> 0.75 ms per 10^6 records, round 2).  Bounds: the text buffer starts 256-byte aligned (hipMalloc) and
+// is allocated with at least 16 bytes of slack behind its n bytes (vt_raw_.ensure(n + 16)), so the aligned word that
+// holds a byte i < n - the only bytes ever asked for - ends at most 7 bytes behind n, inside the allocation.
+struct ByteWindow {
+    const u64* words; u64 nbytes; u64 at = ~0ull; u64 v = 0; u64 oob = 0;
+    __device__ __forceinline__ ByteWindow(const uint8_t* raw, u64 n) : words(reinterpret_cast<const u64*>(raw)), nbytes(n) {}
+    __device__ __forceinline__ uint8_t operator[](u64 i)
+    {
+        if (i >= nbytes) { oob = i | (1ull << 63); return (uint8_t)'\n'; }   // never asked for by a correct walk: reported, not read
+        const u64 wi = i >> 3;
+        if (wi != at) { at = wi; v = words[wi]; }
+        return (uint8_t)(v >> ((i & 7u) * 8u));
+    }
+};
+
 template <bool FILL>
-__device__ bool vt_parse(const uint8_t* __restrict__ raw, u64 lo, u64 hi, VtCounts& c, const VtSink& k)
+__device__ bool vt_parse(ByteWindow& raw, u64 lo, u64 hi, VtCounts& c, const VtSink& k)
 {
     c = VtCounts{0, 0, 0, 0, 0, 0};
     u64 fs = lo, ref_lo = 0;
@@ -468,16 +485,16 @@ __device__ bool vt_parse(const uint8_t* __restrict__ raw, u64 lo, u64 hi, VtCoun
                 u64 e = t;
                 while (e < fe && raw[e] != ',') e++;
                 const u64 len = e - t;
-                const uint8_t* src = raw + t;
+                u64 src = t;                                             // index of the allele's first byte in the text
                 u64 alen = len;
                 if (len && raw[t] == '<' && raw[e - 1] == '>') {
                     if (len == 5 && raw[t + 1] == 'D' && raw[t + 2] == 'E' && raw[t + 3] == 'L') alen = 0;
-                    else if (len == 5 && raw[t + 1] == 'I' && raw[t + 2] == 'N' && raw[t + 3] == 'S') { src = raw + ref_lo; alen = c.reflen; }
+                    else if (len == 5 && raw[t + 1] == 'I' && raw[t + 2] == 'N' && raw[t + 3] == 'S') { src = ref_lo; alen = c.reflen; }
                     else return false;                                   // unsupported SV: warning + skip on the host
                 }
                 if (FILL) {
                     k.altoff[c.nalt] = k.altc_base + c.altc;
-                    for (u64 x = 0; x < alen; x++) k.altchars[k.altc_base + c.altc + x] = src[x];
+                    for (u64 x = 0; x < alen; x++) k.altchars[k.altc_base + c.altc + x] = raw[src + x];
                 }
                 c.nalt++; c.altc += alen;
                 t = e + 1;
@@ -510,22 +527,55 @@ __device__ bool vt_parse(const uint8_t* __restrict__ raw, u64 lo, u64 hi, VtCoun
     return f >= 5;
 }
 
-__global__ void k_vt_lines(const uint8_t* __restrict__ raw, u64 n, u64* __restrict__ flag, VtCtl* ctl)
+// Record-line starts without a flag and an index word per input BYTE (that scratch, 16 B per byte, sent VCFs of more than
+// a few GB to the host tokeniser): a wave owns 1024 bytes of the text (16 per lane); pass 1 counts the line starts of
+// every such block, a scan over the BLOCK counts (8 B per KB of text) numbers them, pass 2 finds them again and writes
+// their positions.  A byte starts a record line iff it follows a newline (or is the first byte) and is neither a
+// newline nor '#'.
+constexpr u64 VT_BLOCK = 1024;
+__device__ __forceinline__ u32 chunk_eq16b(const uint4& a, uint32_t cccc)      // bit i: byte i equals c
 {
-    bool bad = false;
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const uint8_t c = raw[i];
-        if (c == '\r') bad = true;
-        flag[i] = (i == 0 || raw[i - 1] == '\n') && c != '\n' && c != '#';
+    return eq_byte4(a.x, cccc) | (eq_byte4(a.y, cccc) << 4) | (eq_byte4(a.z, cccc) << 8) | (eq_byte4(a.w, cccc) << 12);
+}
+__device__ __forceinline__ u32 vt_line_start_mask(const uint8_t* __restrict__ raw, u64 n, u64 i0, bool& saw_cr)
+{
+    if (i0 >= n) return 0;
+    const uint4 v = *reinterpret_cast<const uint4*>(raw + i0);            // (the text buffer is 256-byte aligned, 16 bytes of slack)
+    const u32 nl = chunk_eq16b(v, 0x0a0a0a0au), hash = chunk_eq16b(v, 0x23232323u);
+    if (chunk_eq16b(v, 0x0d0d0d0du) & (n - i0 >= 16 ? 0xffffu : (1u << (n - i0)) - 1u)) saw_cr = true;
+    const u32 prev_nl = ((nl << 1) | (i0 == 0 || raw[i0 - 1] == '\n' ? 1u : 0u)) & 0xffffu;
+    u32 m = prev_nl & ~nl & ~hash;
+    if (n - i0 < 16) m &= (1u << (n - i0)) - 1u;
+    return m;
+}
+__global__ void __launch_bounds__(256) k_vt_line_count(const uint8_t* __restrict__ raw, u64 n, u64* __restrict__ cnt, VtCtl* ctl)
+{
+    const u64 nblk = (n + VT_BLOCK - 1) / VT_BLOCK;
+    const u32 lane = threadIdx.x & 63;
+    bool cr = false;
+    for (u64 b = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6; b < nblk; b += ((u64)gridDim.x * blockDim.x) >> 6) {
+        u32 c = (u32)__builtin_popcount(vt_line_start_mask(raw, n, b * VT_BLOCK + lane * 16u, cr));
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) cnt[b] = c;
     }
-    if (bad) ctl->bad = 1;
+    if (cr) ctl->bad = 1;
 }
-__global__ void k_vt_scatter(const u64* __restrict__ flag, const u64* __restrict__ idx, u64 n, u64* __restrict__ lstart)
+__global__ void __launch_bounds__(256) k_vt_line_fill(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ base, u64* __restrict__ lstart)
 {
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
-        if (flag[i]) lstart[idx[i]] = i;
+    const u64 nblk = (n + VT_BLOCK - 1) / VT_BLOCK;
+    const u32 lane = threadIdx.x & 63;
+    bool cr = false;
+    for (u64 b = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6; b < nblk; b += ((u64)gridDim.x * blockDim.x) >> 6) {
+        const u64 i0 = b * VT_BLOCK + lane * 16u;
+        u32 m = vt_line_start_mask(raw, n, i0, cr);
+        const u32 c = (u32)__builtin_popcount(m);
+        u32 incl = c;
+        for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += x; }
+        u64 at = base[b] + (incl - c);
+        while (m) { lstart[at++] = i0 + (u32)__builtin_ctz(m); m &= m - 1; }
+    }
 }
-__device__ __forceinline__ u64 vt_line_end(const uint8_t* raw, u64 lo, u64 n)
+__device__ __forceinline__ u64 vt_line_end(ByteWindow& raw, u64 lo, u64 n)
 {
     u64 hi = lo;
     while (hi < n && raw[hi] != '\n') hi++;
@@ -537,9 +587,12 @@ __global__ void k_vt_count(const uint8_t* __restrict__ raw, u64 n, const u64* __
     bool bad = false;
     u64 mx = 0;
     for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < nrec; j += (u64)gridDim.x * blockDim.x) {
-        const u64 lo = lstart[j], hi = vt_line_end(raw, lo, n);
+        ByteWindow win(raw, n);
+        const u64 lo = lstart[j], hi = vt_line_end(win, lo, n);
         VtCounts c;
-        if (!vt_parse<false>(raw, lo, hi, c, VtSink{})) bad = true;
+        if (lo >= n) { ctl->oob = lo | (1ull << 62); bad = true; continue; }
+        if (!vt_parse<false>(win, lo, hi, c, VtSink{})) bad = true;
+        if (win.oob) ctl->oob = win.oob;
         if (r.linelen) r.linelen[j] = hi - lo;                               // index pass of a partitioned run
         else if (c.pos == 0 || c.pos - 1 + c.reflen < c.pos - 1) bad = true; // wrapped positions: host sweep (see run)
         r.pos[j] = c.pos; r.reflen[j] = c.reflen; r.nalt[j] = c.nalt; r.altc[j] = c.altc; r.ngt[j] = c.ngt; r.nall[j] = c.nall;
@@ -572,13 +625,17 @@ __global__ void k_vt_gather(VtRec r, const u32* __restrict__ order, u64 nrec, u6
 struct VtOut { u64* start; u64* reflen; u64* alt0; u64* altoff; uint8_t* altchars; u64* pair0; u64* pa0; int* alleles;
                const u64* altc0; const u64* gtc0; };
 __global__ void k_vt_fill(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ lstart, const u32* __restrict__ order,
-                          u64 nrec, VtOut o, const VtCtl* ctl)
+                          u64 nrec, VtOut o, VtCtl* ctl)
 {
     for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < nrec; j += (u64)gridDim.x * blockDim.x) {
         const u64 lo = lstart[order ? order[j] : j];
         VtCounts c;
         VtSink k{o.altoff + o.alt0[j], o.altc0[j], o.altchars, o.pa0 + o.pair0[j], o.gtc0[j], o.alleles};
-        vt_parse<true>(raw, lo, vt_line_end(raw, lo, n), c, k);
+        ByteWindow win(raw, n);
+        const u64 hi = vt_line_end(win, lo, n);
+        if (lo < n) vt_parse<true>(win, lo, hi, c, k);
+        else ctl->oob = lo | (1ull << 62);
+        if (win.oob) ctl->oob = win.oob;
         o.start[j] = c.pos - 1;
         o.reflen[j] = c.reflen;
     }
@@ -812,19 +869,20 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
 {
     { const char* e = getenv("EDSX_HOST_TOKENIZER"); if (e && atoi(e)) return false; }      // A/B switch for the parity tests
     nrec = 0; max_samples = 0;
-    if (n == 0 || !device_scratch_fits(17 * n)) return false;   // raw text + two u64 arrays per byte
+    if (n == 0 || !device_scratch_fits(6 * n)) return false;   // raw text + the record arrays (a dozen u64 per record line)
     vt_raw_.ensure(n + 16);
-    vt_flag_.ensure(8 * (n + 2)); vt_idx_.ensure(8 * (n + 2));
+    const u64 nblk = (n + VT_BLOCK - 1) / VT_BLOCK;
+    vt_idx_.ensure(8 * (nblk + 2));                            // line starts per 1 KB block of the text
     scan_tmp_.ensure(8 * ((n + 2) / SCAN_TILE + 4));
     ctl_.ensure(8 * 32);
     VtCtl* ctl = reinterpret_cast<VtCtl*>(ctl_.as<u64>() + 16);
     VtCtl h{};
-    h.n = n;
+    h.n = nblk;                                                // element count of the block scan
     EDSX_HIP(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, st));
     EDSX_HIP(hipMemcpyAsync(vt_raw_.ptr, vcf, n, hipMemcpyHostToDevice, st));
     const uint8_t* raw = vt_raw_.as<uint8_t>();
-    hipLaunchKernelGGL(k_vt_lines, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_flag_.as<u64>(), ctl);
-    exclusive_scan_u64(vt_flag_.as<u64>(), vt_idx_.as<u64>(), &ctl->n, &ctl->nrec, scan_tmp_.as<u64>(), st);
+    hipLaunchKernelGGL(k_vt_line_count, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_idx_.as<u64>(), ctl);
+    exclusive_scan_u64(vt_idx_.as<u64>(), vt_idx_.as<u64>(), &ctl->n, &ctl->nrec, scan_tmp_.as<u64>(), st);
     EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
     if (h.bad || h.nrec >= 0xffffffffull) return false;
@@ -832,13 +890,15 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
     stats.total_variants = stats.processed_variants = nr;
     if (nr == 0) return true;
     vt_lstart_.ensure(8 * (nr + 1));
-    hipLaunchKernelGGL(k_vt_scatter, dim3(2048), dim3(256), 0, st, vt_flag_.as<u64>(), vt_idx_.as<u64>(), (u64)n, vt_lstart_.as<u64>());
+    hipLaunchKernelGGL(k_vt_line_fill, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_idx_.as<u64>(), vt_lstart_.as<u64>());
     for (DevBuf* b : {&vt_pos_, &vt_reflen_, &vt_nalt_, &vt_altc_, &vt_ngt_, &vt_nall_, &vt_s1_, &vt_s2_, &vt_s3_, &vt_s4_}) b->ensure(8 * (nr + 2));
     VtRec rec{vt_pos_.as<u64>(), vt_reflen_.as<u64>(), vt_nalt_.as<u64>(), vt_altc_.as<u64>(), vt_ngt_.as<u64>(), vt_nall_.as<u64>(), nullptr};
     hipLaunchKernelGGL(k_vt_count, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_lstart_.as<u64>(), nr, rec, ctl);
     hipLaunchKernelGGL(k_vt_ascending, dim3(1024), dim3(256), 0, st, vt_pos_.as<u64>(), nr, ctl);
     EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
+    if (h.oob) throw DeviceError("VCF tokeniser: byte index " + std::to_string(h.oob & ((1ull << 62) - 1)) + " outside the text of " +
+                                 std::to_string(n) + " bytes (flags " + std::to_string(h.oob >> 62) + ")");
     if (h.bad) return false;
     // The reference's unstable std::sort (:715-718) on (pos, file index) pairs, as on the host path — unless the
     // positions already ascend strictly (the usual VCF) or the caller hands the records over in final order.
@@ -892,8 +952,11 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
     VtOut o{start_.as<u64>(), reflen_.as<u64>(), alt0_.as<u64>(), altoff_.as<u64>(), altchars_.as<uint8_t>(), pair0_.as<u64>(),
             pa0_.as<u64>(), alleles_.as<int>(), vt_s2_.as<u64>(), vt_s4_.as<u64>()};
     hipLaunchKernelGGL(k_vt_fill, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_lstart_.as<u64>(), d_order, nr, o, ctl);
+    EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
     EDSX_HIP(hipGetLastError());
+    if (h.oob) throw DeviceError("VCF tokeniser (fill): byte index " + std::to_string(h.oob & ((1ull << 62) - 1)) + " outside the text of " +
+                                 std::to_string(n) + " bytes (flags " + std::to_string(h.oob >> 62) + ")");
     nrec = nr;
     max_samples = h.max_samples;
     return true;
@@ -906,19 +969,20 @@ bool VcfPipeline::index_device(const uint8_t* vcf, size_t n, hipStream_t st, std
                                std::vector<u64>& line_off, std::vector<u64>& line_len, VcfCounters& stats)
 {
     { const char* e = getenv("EDSX_HOST_TOKENIZER"); if (e && atoi(e)) return false; }
-    if (n == 0 || !device_scratch_fits(17 * n)) return false;
+    if (n == 0 || !device_scratch_fits(6 * n)) return false;
     vt_raw_.ensure(n + 16);
-    vt_flag_.ensure(8 * (n + 2)); vt_idx_.ensure(8 * (n + 2));
+    const u64 nblk = (n + VT_BLOCK - 1) / VT_BLOCK;
+    vt_idx_.ensure(8 * (nblk + 2));                            // line starts per 1 KB block of the text
     scan_tmp_.ensure(8 * ((n + 2) / SCAN_TILE + 4));
     ctl_.ensure(8 * 32);
     VtCtl* ctl = reinterpret_cast<VtCtl*>(ctl_.as<u64>() + 16);
     VtCtl h{};
-    h.n = n;
+    h.n = nblk;                                                // element count of the block scan
     EDSX_HIP(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, st));
     EDSX_HIP(hipMemcpyAsync(vt_raw_.ptr, vcf, n, hipMemcpyHostToDevice, st));
     const uint8_t* raw = vt_raw_.as<uint8_t>();
-    hipLaunchKernelGGL(k_vt_lines, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_flag_.as<u64>(), ctl);
-    exclusive_scan_u64(vt_flag_.as<u64>(), vt_idx_.as<u64>(), &ctl->n, &ctl->nrec, scan_tmp_.as<u64>(), st);
+    hipLaunchKernelGGL(k_vt_line_count, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_idx_.as<u64>(), ctl);
+    exclusive_scan_u64(vt_idx_.as<u64>(), vt_idx_.as<u64>(), &ctl->n, &ctl->nrec, scan_tmp_.as<u64>(), st);
     EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
     if (h.bad || h.nrec >= 0xffffffffull) return false;
@@ -928,7 +992,7 @@ bool VcfPipeline::index_device(const uint8_t* vcf, size_t n, hipStream_t st, std
     pos.assign(nr, 0); reflen.assign(nr, 0); line_off.assign(nr, 0); line_len.assign(nr, 0);
     if (nr == 0) return true;
     vt_lstart_.ensure(8 * (nr + 1));
-    hipLaunchKernelGGL(k_vt_scatter, dim3(2048), dim3(256), 0, st, vt_flag_.as<u64>(), vt_idx_.as<u64>(), (u64)n, vt_lstart_.as<u64>());
+    hipLaunchKernelGGL(k_vt_line_fill, dim3(2048), dim3(256), 0, st, raw, (u64)n, vt_idx_.as<u64>(), vt_lstart_.as<u64>());
     for (DevBuf* b : {&vt_pos_, &vt_reflen_, &vt_nalt_, &vt_altc_, &vt_ngt_, &vt_nall_, &vt_s1_}) b->ensure(8 * (nr + 2));
     VtRec rec{vt_pos_.as<u64>(), vt_reflen_.as<u64>(), vt_nalt_.as<u64>(), vt_altc_.as<u64>(), vt_ngt_.as<u64>(), vt_nall_.as<u64>(),
               vt_s1_.as<u64>()};

@@ -43,7 +43,7 @@ private:
     bool tokenised_on_device_ = false;
     bool tokenize_device(const uint8_t* vcf, size_t n, bool presorted, hipStream_t st, u64& nrec, u64& max_samples,
                          VcfCounters& stats);
-    DevBuf vt_raw_, vt_flag_, vt_idx_, vt_lstart_, vt_pos_, vt_reflen_, vt_nalt_, vt_altc_, vt_ngt_, vt_nall_, vt_s1_, vt_s2_, vt_s3_,
+    DevBuf vt_raw_, vt_idx_, vt_lstart_, vt_pos_, vt_reflen_, vt_nalt_, vt_altc_, vt_ngt_, vt_nall_, vt_s1_, vt_s2_, vt_s3_,
            vt_s4_, vt_order_, vt_sorttmp_;
     DevBuf d_fasta_, refc_, blkpre_, scan_tmp_, ctl_, start_, reflen_, alt0_, altoff_, altchars_, pair0_, pa0_, alleles_,
            ends_, flag_, gidx_, grp_r0_, g_gs_, g_spanlen_, g_cs_, g_nraw_, g_rawchars_, g_ndist_, g_bitwords_, g_eds_,

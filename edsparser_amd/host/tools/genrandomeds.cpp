@@ -56,11 +56,14 @@ int main(int argc, char** argv)
         const unsigned long seed = opts.has("seed") ? opts.get_unsigned("seed", 0) : std::random_device{}();
         auto fail = [&](const char* msg) { std::cerr << "Error: " << msg << "\n"; tool::print_performance(timer); return 1; };
         if (ref_size_mb == 0) return fail("Reference size must be greater than 0 MB");
-        if (variability < 0.0 || variability > 1.0) return fail("Variability must be between 0.0 and 1.0");
+        if (!(variability >= 0.0 && variability <= 1.0)) return fail("Variability must be between 0.0 and 1.0");
         if (min_alt < 2) return fail("Minimum alternatives must be at least 2");
+        // (range checks before the values are narrowed to the library's 32-bit parameters)
+        if (min_alt > 0xffffffffUL || max_alt > 0xffffffffUL) return fail("Maximum alternatives above 16 are not supported by this build");
+        if (var_len_max > 0xffffffffUL) return fail("Variant length max above 63 is not supported by this build");
         if (max_alt < min_alt) return fail("Maximum alternatives must be >= minimum alternatives");
         if (var_len_max == 0) return fail("Variant length max must be greater than 0");
-        if (snp_ratio < 0.0 || snp_ratio > 1.0) return fail("SNP ratio must be between 0.0 and 1.0");
+        if (!(snp_ratio >= 0.0 && snp_ratio <= 1.0)) return fail("SNP ratio must be between 0.0 and 1.0");
         if (alphabet.empty()) return fail("Alphabet cannot be empty");
 
         const uint64_t total_bp = (uint64_t)ref_size_mb * 1000000ull;

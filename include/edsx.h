@@ -210,6 +210,14 @@ int  edsx_multi_last_partition(const edsx_multi* m, int* partitioned, int* chain
 void edsx_set_timing(edsx_ctx* ctx, int enabled);
 int  edsx_get_timing(edsx_ctx* ctx, const char** names, float* total_ms, int* launches, int cap);
 
+/* ---- synthetic VCF + FASTA of BASELINE configs[3]'s shape, generated in HBM ----
+ * One FASTA record of ref_len uniform ACGT bases in 60-column lines; n_records record lines with strictly ascending
+ * POS, 70 % SNP / 15 % insertion of 1..10 bases / 15 % deletion of 1..10 bases (REF spans them: a few per cent of the
+ * records overlap the next one), n_samples diploid phased samples, each allele ALT with p = 0.3.  Counter-based: the
+ * text depends on the parameters only.  Needs ref_len >= 64 and n_records <= ref_len / 16. */
+int edsx_genvcf(edsx_ctx* ctx, uint64_t ref_len, uint64_t n_records, uint32_t n_samples, uint64_t seed,
+                edsx_buf* vcf, edsx_buf* fasta);
+
 /* ---- synthetic genrandomeds-shaped alignment, generated in HBM (bench / tests) ----
  * Rows 0..n_rows-1 of alignment columns [col0, col0+n_cols) of a virtual alignment, one line per
  * row, headers ">s<row>", trailing newline.  Bytes depend only on (seed, global column, row), so a
@@ -218,6 +226,12 @@ size_t edsx_msa_synth_size(uint32_t n_rows, uint64_t n_cols);
 int edsx_msa_synth_device(edsx_ctx* ctx, uint8_t* d_out, size_t capacity, uint32_t n_rows,
                           uint64_t col0, uint64_t n_cols, double variant_fraction, uint64_t seed,
                           void* stream, size_t* written);
+/* The same alignment with every header padded with blanks (">s<row>    ...") so that each row's first column lies a
+ * multiple of row_align bytes (a power of two, e.g. 128) from the start of the image: the layout an upload that places
+ * the rows for the column scan produces.  row_align <= 1: the plain image above.  Same cells, same outputs. */
+size_t edsx_msa_synth_size_aligned(uint32_t n_rows, uint64_t n_cols, uint32_t row_align);
+int edsx_msa_synth_device_aligned(edsx_ctx* ctx, uint8_t* d_out, size_t capacity, uint32_t n_rows, uint64_t col0, uint64_t n_cols,
+                                  double variant_fraction, uint64_t seed, uint32_t row_align, void* stream, size_t* written);
 
 #ifdef __cplusplus
 }

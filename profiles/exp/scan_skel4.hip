@@ -61,6 +61,38 @@ __global__ void __launch_bounds__(512, 4) k_skel(const uint8_t* __restrict__ f, 
     if (ntiles == 0) pad[tid] = 0;
 }
 
+// nine aligned 16-byte chunks per row (what a byte-unaligned 128-byte piece costs when it is fetched as aligned chunks):
+// 56 row groups x 9 chunks = 504 threads, 896 rows; useful bytes = 896 rows x 128 B per tile
+__global__ void __launch_bounds__(512, 4) k_skel9(const uint8_t* __restrict__ f, const u64* __restrict__ row_start, u64 ntiles, u64* __restrict__ V)
+{
+    extern __shared__ uint8_t pad[];
+    __shared__ u32 D[64];
+    const u32 tid = threadIdx.x, j = tid % 9u, sub = tid / 9u;
+    if (tid < 64) D[tid] = 0;
+    u64 tile;
+    { const u64 nt = ntiles, b = blockIdx.x, per = nt / 8, rem = nt % 8, x = b % 8, k = b / 8; tile = x * per + (x < rem ? x : rem) + k; }
+    const u64 q = tile * 128ull + j * 16;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    if (sub < 56) {
+        const uint4 ref = load16u(f + row_start[0] + q);
+        const ulonglong2* rp = reinterpret_cast<const ulonglong2*>(row_start + sub * 16u);
+        ulonglong2 rv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) rv[i] = rp[i];
+        uint4 d[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { d[2 * i] = load16u(f + rv[i].x + q); d[2 * i + 1] = load16u(f + rv[i].y + q); }
+#pragma unroll
+        for (int it = 0; it < 16; it++) { acc.x |= d[it].x ^ ref.x; acc.y |= d[it].y ^ ref.y; acc.z |= d[it].z ^ ref.z; acc.w |= d[it].w ^ ref.w; }
+    }
+    u32 diff = (acc.x | acc.y | acc.z | acc.w) != 0;
+    __syncthreads();
+    if (diff) atomicOr(&D[j & 63], 1u << (tid & 31));
+    __syncthreads();
+    if (tid < 2) V[tile * 2 + tid] = D[tid] | ((u64)D[tid + 2] << 32);
+    if (ntiles == 0) pad[tid] = 0;
+}
+
 int main()
 {
     const u64 S = 1000, L = 20000000, OCC2 = 64 * 1024;
@@ -93,7 +125,16 @@ int main()
     timeit("Aa16  1000 rows x 128 B, 16-byte aligned pieces (offset 16)", [&] { k_skel<<<(unsigned)(L / 128), 512, OCC2>>>(f, d_rs, 0, L / 128, V); });
     set_rows(64, stride_a, S);
     timeit("Aa64  1000 rows x 128 B, 64-byte aligned pieces (offset 64)", [&] { k_skel<<<(unsigned)(L / 128), 512, OCC2>>>(f, d_rs, 0, L / 128, V); });
-    for (u32 wl = 1; wl <= 3; wl++) {
+    CK(hipFuncSetAttribute((const void*)k_skel9, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OCC2));
+    for (u64 off : {16ull, 4ull, 5ull}) {
+        char nm[128];
+        set_rows(off, stride_a, S);
+        snprintf(nm, sizeof nm, "A9    896 rows x 9 chunks of 16 B (144 B), row offset %llu (TB/s of the 128 useful bytes, x 0.896 rows)", off);
+        timeit(nm, [&] { k_skel9<<<(unsigned)(L / 128), 512, OCC2>>>(f, d_rs, L / 128, V); });
+        snprintf(nm, sizeof nm, "A     1000 rows x 128 B, row offset %llu", off);
+        timeit(nm, [&] { k_skel<<<(unsigned)(L / 128), 512, OCC2>>>(f, d_rs, 0, L / 128, V); });
+    }
+    for (u32 wl = 1; wl <= 1; wl++) {
         const u64 rows = S >> wl, Lw = L << wl;          // same bytes: fewer, longer rows
         char nm[128];
         set_rows(5, Lw + 7, rows);

@@ -397,3 +397,30 @@ def test_dense_variant_columns_grow_the_column_store(ctx, S, L, vf):
     assert bytes(d_eds[:E].cpu().numpy()) == oe
     assert bytes(d_seds[:Q].cpu().numpy()) == os_
     fresh.close()
+
+
+def test_host_call_uploads_large_alignments_as_an_aligned_row_image(ctx):
+    """edsx_msa_transform re-lays plain uniform alignments of 1 MB and more as a row image with every row on a multiple
+    of 128 bytes (csrc/multi_gpu.hip upload_row_image); smaller ones and odd files are copied as they are.  Same bytes
+    out: one-line and wrapped rows, header lengths that change from row to row, with and without the final newline,
+    context lengths, and a ragged file (whose error the transform words)."""
+    import edsparser_amd
+    rng = random.Random(4242)
+    for it, (S, L, lw, nl) in enumerate([(5, 300_000, None, True), (9, 150_000, 60, True), (3, 400_000, 70_001, False),
+                                          (12, 100_000, None, False), (2, 600_000, 7, True)]):
+        msa = random_msa(rng, S=S, L=L, lw=lw, trailing_newline=nl, p_var=0.03)
+        assert len(msa) >= 1 << 20
+        lines = msa.split(b"\n")                       # headers of different lengths: the rows are not equally spaced
+        k = 0
+        for i, ln in enumerate(lines):
+            if ln.startswith(b">"):
+                lines[i] = ln + b"x" * (k % 5)
+                k += 1
+        msa = b"\n".join(lines)
+        for l in ((0, 4) if it < 2 else (0,)):
+            assert ctx.msa_transform(msa, l) == o.msa(msa, l), (it, l)
+    bad = bytearray(random_msa(rng, S=4, L=400_000))
+    del bad[-5:-3]                                     # the last row is two columns short
+    with pytest.raises(edsparser_amd.EdsxError) as ei:
+        ctx.msa_transform(bytes(bad), 0)
+    assert "Invalid MSA" in str(ei.value)

@@ -280,3 +280,40 @@ def test_large_outputs_every_size_remainder(ctx):
         got = ctx.vcf_transform(vcf, fasta, 0)
         assert len(got[0]) >= 16 << 20
         assert got == want, extra
+
+
+def test_text_length_every_remainder_mod_8_with_and_without_final_newline(ctx):
+    """The device tokeniser reads the text through aligned 8-byte words (ByteWindow, csrc/vcf_device.hip): the last line
+    may end anywhere inside its word.  Text lengths 0..7 modulo 8 (a comment line of adjustable length in front), with
+    and without the final newline, last record with a long ALT, an <INS> (copies REF) and a <DEL>; and a text whose
+    length is just below / at / above multiples of 256 (the allocation granule of the text buffer)."""
+    rng = random.Random(88)
+    base_vcf, fasta = _random_vcf(rng, 2000, 60, 4, 60)
+    lines = base_vcf.decode().split("\n")
+    head, body = lines[:2], [x for x in lines[2:] if x]
+    ref = "".join(fasta.decode().split("\n")[1:])
+    last_pos = 1990
+    tails = [
+        "chr1\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t0|1\t1|1\t0|0\t1|0" % (last_pos, ref[last_pos - 1], ref[last_pos - 1] + "ACGTACGTAC"),
+        "chr1\t%d\t.\t%s\t<INS>\t.\tPASS\t.\tGT\t0|1\t1|1\t0|0\t1|0" % (last_pos, ref[last_pos - 1:last_pos + 4]),
+        "chr1\t%d\t.\t%s\t<DEL>\t.\tPASS\t.\tGT\t0|1\t1|1\t0|0\t1|0" % (last_pos, ref[last_pos - 1:last_pos + 2]),
+    ]
+    body = [b for b in body if int(b.split("\t")[1]) < last_pos - 12]
+    seen = set()
+    for tail in tails:
+        for pad in range(0, 8):
+            for nl in ("\n", ""):
+                vcf = ("\n".join([head[0], "##pad=" + "x" * pad, head[1]] + body + [tail]) + nl).encode()
+                seen.add((len(vcf) % 8, nl))
+                got = _run(ctx, vcf, fasta, 0)
+                assert ctx.vcf_tokenised_on_device()
+                assert got == _want(vcf, fasta), (tail[:30], pad, nl)
+    assert len(seen) == 16
+    for target in (255, 256, 257, 511, 512, 513, 4095, 4096, 4097):
+        stem = "\n".join([head[0], head[1]] + body[:3] + [tails[0]])
+        padn = target - len(stem) - len("##pad=\n")
+        if padn < 0:
+            continue
+        vcf = ("\n".join([head[0], "##pad=" + "x" * padn, head[1]] + body[:3] + [tails[0]])).encode()
+        assert len(vcf) == target
+        assert _run(ctx, vcf, fasta, 0) == _want(vcf, fasta), target
