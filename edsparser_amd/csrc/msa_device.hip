@@ -748,9 +748,12 @@ __device__ __forceinline__ void fused_group_run(const K1Params& p, const uint8_t
     }
 }
 
-template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW, bool ROWS64 = false>
+// BIG: more rows than the LDS holds (no row-start table, no column image there): row starts are read from HBM, the
+// variant bytes go straight to vc.
+template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW, bool ROWS64 = false, bool BIG = false>
 __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
 {
+    static_assert(!BIG || (!HOLD && !LANEROWS && !ROWS64), "BIG is the plain variant");
     extern __shared__ __attribute__((aligned(16))) uint8_t colbuf[];
     __shared__ __attribute__((aligned(16))) u32 D[256];
     __shared__ u32 pre[256];
@@ -787,8 +790,8 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
     // eight 16-byte loads that hit L1/L2 - so a wave issues its data loads without waiting for the workgroup.)
     constexpr bool DIRECT_OK = HOLD && LANEROWS;
     const bool direct = DIRECT_OK && full_tile;                // workgroup-uniform
-    u64* rs = reinterpret_cast<u64*>(colbuf);
-    if (!direct) for (u32 r = tid; r < p.S; r += T) rs[r] = p.row_start[r];
+    const u64* rs = BIG ? p.row_start : reinterpret_cast<const u64*>(colbuf);
+    if (!direct && !BIG) for (u32 r = tid; r < p.S; r += T) reinterpret_cast<u64*>(colbuf)[r] = p.row_start[r];
     if (tid < 256) { D[tid] = 0; CS[tid] = 0; }
     if (tid == 0) { ncand_sh = 0; nst_sh = 0; }
     if (!direct) __syncthreads();
@@ -1013,7 +1016,36 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                 for (u32 ci = wv; ci < ncand; ci += TAIL_WAVES)
                     fused_group_run<ROWS64>(p, colbuf, uniform32((u32)clist[ci]), slot_base, lane, vmask, nl, loff);
             }
-        } } else
+        } } else if constexpr (BIG) {
+            if (tid == 0) {
+                slot_base_sh = base_r;
+                if (base_r + nv > p.vc_cap_cols) atomicOr(&p.hdr->status, (u64)ST_VC_OVERFLOW);
+            }
+            __syncthreads();
+            slot_base = slot_base_sh;
+            overflow = slot_base + nv > p.vc_cap_cols;
+            if (tid < (cpr + 3u) / 4u) {                       // V words + per-word slot base
+                const u64 wi = q0 / 64 + tid;
+                if (wi * 64 < p.Draw) {
+                    p.Vraw[wi] = (u64)D[4 * tid] | ((u64)D[4 * tid + 1] << 16) | ((u64)D[4 * tid + 2] << 32) | ((u64)D[4 * tid + 3] << 48);
+                    p.word_slot[wi] = slot_base + pre_of(4 * tid);
+                }
+            }
+            if (nv && !overflow && V16) {
+                u32 m = V16, idx = pre_of(j);
+                while (m) {
+                    const int i = __builtin_ctz(m);
+                    m &= m - 1;
+                    uint8_t* dst = p.vc + (slot_base + idx) * (u64)p.Spad;
+                    for (u32 r = sub; r < p.S; r += RI) {
+                        const u32 ch = f[p.row_start[r] + q + i];
+                        if (ch == '\n') bad = 1;
+                        dst[r] = (uint8_t)ch;
+                    }
+                    idx++;
+                }
+            }
+        } else
         for (u32 b0 = 0; b0 < nv || b0 == 0; b0 += cap) {
             if (V16 && nv) {
                 u32 idx = pre_of(j);
@@ -1187,18 +1219,29 @@ __global__ void k_popc_words(const u64* __restrict__ H, u64* __restrict__ cnt, u
 //   key[S] u64 | rep_row[S] u32 | run[S] u32 | gid[S] u16
 // ---------------------------------------------------------------------------------------------
 constexpr int GT = 512;
-constexpr u32 GID_NONE = 0xffffu;
-
-struct SegLds {
-    u64* key; u32* rep_row; u32* run; uint16_t* gid;
-    __device__ SegLds(uint8_t* base, u32 S)
+// BIG (more rows than the LDS holds, MsaPipeline::LDS_ROWS): the same arrays in a per-workgroup slice of HBM scratch,
+// group ids of 32 bits (a segment may have more than 65535 distinct strings).
+template <bool BIG> struct SegLdsT {
+    using gid_t = std::conditional_t<BIG, u32, uint16_t>;
+    static constexpr u32 NONE = BIG ? 0xffffffffu : 0xffffu;
+    u64* key; u32* rep_row; u32* run; gid_t* gid;
+    __device__ SegLdsT(uint8_t* base, u32 S)
     {
         key = reinterpret_cast<u64*>(base);
         rep_row = reinterpret_cast<u32*>(base + (size_t)8 * S);
         run = reinterpret_cast<u32*>(base + (size_t)12 * S);
-        gid = reinterpret_cast<uint16_t*>(base + (size_t)16 * S);
+        gid = reinterpret_cast<gid_t*>(base + (size_t)16 * S);
     }
+    __host__ __device__ static size_t bytes(u32 S) { return (size_t)(16 + sizeof(gid_t)) * S; }
 };
+// tables of the generic emitter's .seds walk (k_emit_variant): per 64-row block the bytes / starts (u32) and ids of its
+// groups, per row its offset inside its group's part of the block (u16) and the index of its group in the block (u8),
+// per block the number of groups (u8)
+template <bool BIG> __host__ __device__ inline size_t walk_table_bytes(u32 S)
+{
+    const size_t nblk = (S + 63u) >> 6, S2 = (S + 1u) & ~1u;
+    return nblk * (256 + 64 * sizeof(typename SegLdsT<BIG>::gid_t)) + S2 * 3 + nblk + 16;
+}
 
 // Cells of one segment.  Read from HBM a cell costs a chain of dependent loads (V word, slot table,
 // vc byte); segments of up to STAGE_COLS pure variant columns are first copied into LDS (`st`), which
@@ -1343,8 +1386,11 @@ struct HtLds {
 };
 
 // returns k (number of distinct strings); fills lds.gid[], lds.rep_row[0..k)
-__device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* rep_sh, const uint8_t* st, u32 cap)
+template <bool BIG>
+__device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLdsT<BIG>& lds, u32* rep_sh, const uint8_t* st, u32 cap)
 {
+    using gid_t = typename SegLdsT<BIG>::gid_t;
+    constexpr u32 GID_NONE = SegLdsT<BIG>::NONE;
     const u32 S = mv.S;
     const SegCells sc{mv, a, st, cap};
     const bool exact = (b - a) <= 8;
@@ -1390,7 +1436,7 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
     else make_keys(std::integral_constant<int, 4>{});
     if (saw_nl) atomicOr(&mv.hdr->status, (u64)(ST_LAYOUT | ST_NEWLINE_IN_DATA));   // a row is ragged
 
-    if (S <= HT_MAX_ROWS) {
+    if (!BIG && S <= HT_MAX_ROWS) {
         const u32 hsz = ht_size_of(S);
         HtLds ht(reinterpret_cast<uint8_t*>(lds.gid + ((S + 7) & ~7u)), hsz);
         for (u32 i = threadIdx.x; i < hsz; i += GT) ht.tabm[i] = 0xffffffffu;
@@ -1435,7 +1481,7 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
             __syncthreads();                              // rep_row[] is rewritten below
             for (u32 j = 0, r = threadIdx.x; r < S; r += GT, j++) {
                 const u32 f = lds.rep_row[r];
-                lds.gid[r] = (uint16_t)myg[j];
+                lds.gid[r] = (gid_t)myg[j];
                 (void)f;
             }
             __syncthreads();
@@ -1462,7 +1508,7 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLds& lds, u32* 
         for (u32 r = cursor; r < S; r += GT) {
             if (lds.gid[r] == GID_NONE && lds.key[r] == rk &&
                 (exact || r == rep || seg_rows_equal(sc, a, b, r, rep)))
-                lds.gid[r] = (uint16_t)g;
+                lds.gid[r] = (gid_t)g;
         }
         if (threadIdx.x == 0) lds.rep_row[g] = rep;
         g++;
@@ -1476,11 +1522,12 @@ struct SegParams {
     const u64* list; const u64* list_n;       // when set: only these segments (left over by the fast path)
     u32 stage_cols = 0, stage_off = 0;        // LDS column staging: capacity in columns, byte offset in the dynamic LDS
     // grouping cache (count -> emit): item `it` of the list (or segment `it`) keeps k, its group ids and first rows
-    uint8_t* gcache = nullptr; u64 gcache_cap = 0; u32 gcache_stride = 0;
+    uint8_t* gcache = nullptr; u64 gcache_cap = 0; u64 gcache_stride = 0;
     u64* long_list = nullptr; u64* long_count = nullptr;   // common segments for k_emit_common_long (see common_is_long)
+    uint8_t* scratch = nullptr; u64 scratch_stride = 0;    // BIG: per-workgroup slice of HBM for the row tables
 };
-// cache entry: u32 k, pad; u16 gid[S (rounded up to 8)]; u32 rep_row[S]
-__host__ __device__ inline u32 gcache_stride_of(u32 S) { return 16u + ((S + 7u) & ~7u) * 2u + S * 4u; }
+// cache entry: u32 k, pad; gid[S (rounded up to 8)] (u16, BIG: u32); u32 rep_row[S]
+__host__ __device__ inline u64 gcache_stride_of(u32 S, bool big) { return 16ull + (u64)((S + 7u) & ~7u) * (big ? 4u : 2u) + (u64)S * 4u; }
 
 // ---- common segments (msa_transforms.cpp:245-258: "{" + the reference row's text + "}" and "{0}") ---------------------
 // A thread per common segment (they alternate with the variant ones): four coalesced table reads, then the few
@@ -1566,12 +1613,14 @@ __global__ void __launch_bounds__(256) k_emit_common_long(MsaView mv, const u64*
 }
 
 // K3: per-segment output sizes.  common: "{" ref "}" and "{0}"; variant: see generate_output.
+template <bool BIG>
 __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     __shared__ u32 rep_sh;
     __shared__ u64 sum_sh;
-    SegLds lds(lds_raw, p.mv.S);
+    using gid_t = typename SegLdsT<BIG>::gid_t;
+    SegLdsT<BIG> lds(BIG ? p.scratch + blockIdx.x * p.scratch_stride : lds_raw, p.mv.S);
     if (p.mv.hdr->status) return;                     // vc overflow: the host grows vc and replans
     // without a work list: every segment.  Variant and common segments alternate (item `it` = the it-th variant segment);
     // the common ones are a thread each
@@ -1593,8 +1642,8 @@ __global__ void __launch_bounds__(GT) k_seg_count(SegParams p)
         const u32 k = group_segment(p.mv, a, b, lds, &rep_sh, st, cap);
         if (it < p.gcache_cap) {                             // the emitter takes the grouping from here
             uint8_t* ce = p.gcache + it * (u64)p.gcache_stride;
-            uint16_t* cg = reinterpret_cast<uint16_t*>(ce + 16);
-            u32* cr = reinterpret_cast<u32*>(ce + 16 + ((p.mv.S + 7u) & ~7u) * 2u);
+            gid_t* cg = reinterpret_cast<gid_t*>(ce + 16);
+            u32* cr = reinterpret_cast<u32*>(ce + 16 + (size_t)((p.mv.S + 7u) & ~7u) * sizeof(gid_t));
             if (threadIdx.x == 0) *reinterpret_cast<u32*>(ce) = k;
             for (u32 r = threadIdx.x; r < p.mv.S; r += GT) cg[r] = lds.gid[r];
             for (u32 g = threadIdx.x; g < k; g += GT) cr[g] = lds.rep_row[g];
@@ -1620,7 +1669,8 @@ struct EmitParams {
     const u64* eds_off; const u64* seds_off; uint8_t* eds; uint8_t* seds; u64 nwords;
     const u64* list; const u64* list_n;
     u32 stage_cols = 0, stage_off = 0;
-    const uint8_t* gcache = nullptr; u64 gcache_cap = 0; u32 gcache_stride = 0;      // see SegParams
+    const uint8_t* gcache = nullptr; u64 gcache_cap = 0; u64 gcache_stride = 0;      // see SegParams
+    uint8_t* scratch = nullptr; u64 scratch_stride = 0;
     const u64* list2 = nullptr; const u64* list2_n = nullptr; const uint8_t* gcache2 = nullptr;   // a second work list behind the first
 };
 
@@ -1632,13 +1682,16 @@ __device__ __forceinline__ void write_decimal(uint8_t* dst, u32 v, u32 nd)
     for (int i = (int)nd - 1; i >= 0; i--) { dst[i] = (uint8_t)('0' + v % 10u); v /= 10u; }
 }
 
+template <bool BIG>
 __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     __shared__ u32 rep_sh;
     const MsaView& mv = p.mv;
     const u32 S = mv.S;
-    SegLds lds(lds_raw, S);
+    using gid_t = typename SegLdsT<BIG>::gid_t;
+    uint8_t* const tables = BIG ? p.scratch + blockIdx.x * p.scratch_stride : lds_raw;
+    SegLdsT<BIG> lds(tables, S);
     if (mv.hdr->status) return;
     const u64 nseg = *p.nseg_ptr, p0 = mv.vbit(0) ? 0 : 1;      // items as in k_seg_count
     const u64 n1 = p.list ? *p.list_n : (nseg > p0 ? (nseg - p0 + 1) / 2 : 0);
@@ -1654,8 +1707,8 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
         u32 k;
         if (it < p.gcache_cap) {                             // grouped by k_seg_count already
             const uint8_t* ce = (second ? p.gcache2 : p.gcache) + it * (u64)p.gcache_stride;
-            const uint16_t* cg = reinterpret_cast<const uint16_t*>(ce + 16);
-            const u32* cr = reinterpret_cast<const u32*>(ce + 16 + ((S + 7u) & ~7u) * 2u);
+            const gid_t* cg = reinterpret_cast<const gid_t*>(ce + 16);
+            const u32* cr = reinterpret_cast<const u32*>(ce + 16 + (size_t)((S + 7u) & ~7u) * sizeof(gid_t));
             k = *reinterpret_cast<const u32*>(ce);
             __syncthreads();                                  // (the previous segment's readers of gid / rep_row are done)
             for (u32 r = threadIdx.x; r < S; r += GT) lds.gid[r] = cg[r];
@@ -1706,8 +1759,9 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
         // totals into start offsets (a block's groups are distinct: one lane each); (C) all waves store their tokens.
         // Otherwise (no staging area: very many rows) wave 0 walks the rows block by block.
         const u32 nblk = (S + 63u) >> 6, S2 = (S + 1u) & ~1u, wv = uniform32(threadIdx.x >> 6);
-        const size_t walk_bytes = (size_t)nblk * 384 + (size_t)S2 * 2 + S2 + nblk + 16;
-        const bool par = p.stage_cols != 0 && walk_bytes <= (size_t)p.stage_cols * (8 + (size_t)mv.Spad);
+        const size_t walk_bytes = walk_table_bytes<BIG>(S);
+        // (BIG: the tables live behind the row tables in the workgroup's slice of HBM scratch)
+        const bool par = BIG || (p.stage_cols != 0 && walk_bytes <= (size_t)p.stage_cols * (8 + (size_t)mv.Spad));
         auto token_of = [&](u32 r, u32 tl) -> u64 {            // "ddd," little-endian: first digit in byte 0
             u64 tok = (u64)',' << (8 * (tl - 1));
             u32 v = r + 1;
@@ -1722,11 +1776,12 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
             if (tl >= 6) for (u32 i = 5; i < tl; i++) dst[i] = (uint8_t)(tok >> (8 * i));
         };
         if (par) {
-            uint8_t* wb = lds_raw + p.stage_off;
+            uint8_t* wb = BIG ? tables + ((SegLdsT<BIG>::bytes(S) + 15) & ~(size_t)15) : lds_raw + p.stage_off;
+            constexpr size_t PER_BLK = 256 + 64 * sizeof(gid_t);
             u32* LT = reinterpret_cast<u32*>(wb);                                  // [block][i]: bytes of the block's i-th group, then its start
-            uint16_t* LG = reinterpret_cast<uint16_t*>(wb + (size_t)nblk * 256);   // [block][i]: that group
-            uint16_t* REL = reinterpret_cast<uint16_t*>(wb + (size_t)nblk * 384);  // [row]: bytes of the earlier rows of its group in its block
-            uint8_t* IDX = wb + (size_t)nblk * 384 + (size_t)S2 * 2;               // [row]: index of its group in its block's list
+            gid_t* LG = reinterpret_cast<gid_t*>(wb + (size_t)nblk * 256);         // [block][i]: that group
+            uint16_t* REL = reinterpret_cast<uint16_t*>(wb + (size_t)nblk * PER_BLK);  // [row]: bytes of the earlier rows of its group in its block
+            uint8_t* IDX = wb + (size_t)nblk * PER_BLK + (size_t)S2 * 2;           // [row]: index of its group in its block's list
             uint8_t* NG = IDX + S2;                                                // [block]: distinct groups
             for (u32 blk = wv; blk < nblk; blk += GT / 64) {                       // (A)
                 const u32 r = blk * 64u + lane;
@@ -1743,7 +1798,7 @@ __global__ void __launch_bounds__(GT) k_emit_variant(EmitParams p)
                     const u64 m = ballot64(valid && g == g0);
                     if (valid && g == g0) { myrel = mbcnt(m & maskA) * tlA + mbcnt(m & ~maskA) * (tlA + 1); myidx = idx; }
                     if (lane == (u32)leader) {
-                        LG[blk * 64u + idx] = (uint16_t)g0;
+                        LG[blk * 64u + idx] = (gid_t)g0;
                         LT[blk * 64u + idx] = (u32)__builtin_popcountll(m & maskA) * tlA + (u32)__builtin_popcountll(m & ~maskA) * (tlA + 1);
                     }
                     idx++;
@@ -1845,21 +1900,28 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
     if (mv.hdr->status) return;                           // vc overflow: slots past the capacity exist; the host grows vc and replans
     const u64 nseg = *p.nseg_ptr;
     const u64 p0 = mv.vbit(0) ? 0 : 1;                   // variant and common segments alternate
-    if (blockIdx.x == 0 && threadIdx.x == 0) mv.hdr->nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
-    const u64 stride = (u64)gridDim.x * blockDim.x, rounds = (nseg + stride - 1) / stride;
-    for (u64 rd = 0; rd < rounds; rd++) {
-        const u64 seg = rd * stride + blockIdx.x * (u64)blockDim.x + threadIdx.x;
-        u64 work_vi = 0, work_cm = 0, work_wide = 0;
-        if (seg < nseg) do {
+    const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) mv.hdr->nvs = nvs;
+    auto common = [&](u64 seg, u64 a, u64 b) {
+        p.eds_len[seg] = 2 + (b - a);
+        p.seds_len[seg] = 3;
+        p.segmeta[seg] = 0;
+        if (common_is_long(b - a)) p.long_list[atomicAdd(p.long_count, 1ull)] = seg;
+    };
+    // A thread per VARIANT segment: it also does the common segment behind it (and the one in front of the first), so
+    // every lane of a wave walks the same chain of dependent loads (segment start -> slot -> record info) instead of
+    // every other lane idling through it.
+    if (nvs == 0) {                                      // a single common segment
+        if (blockIdx.x == 0 && threadIdx.x == 0 && nseg) common(0, p.seg_start[0], p.seg_start[1]);
+        return;
+    }
+    for (u64 vi = blockIdx.x * (u64)blockDim.x + threadIdx.x; vi < nvs; vi += (u64)gridDim.x * blockDim.x) {
+        const u64 seg = 2 * vi + p0;
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
-        if (!mv.vbit(a)) {
-            p.eds_len[seg] = 2 + (b - a);
-            p.seds_len[seg] = 3;
-            p.segmeta[seg] = 0;
-            if (common_is_long(b - a)) p.long_list[atomicAdd(p.long_count, 1ull)] = seg;
-            break;
-        }
-        const u64 vi = (seg - p0) >> 1;
+        if (vi == 0 && p0) common(0, p.seg_start[0], a);
+        if (seg + 1 < nseg) common(seg + 1, b, p.seg_start[seg + 2]);
+        u64 work_cm = 0, work_wide = 0;
+        bool done = false;
         if (p.Fraw && ((p.Fraw[a >> 6] >> (a & 63)) & 1ull)) {           // a run the column scan grouped itself?
             const u64 slot = mv.slot(a);
             const u32 info = p.rec_info[slot];
@@ -1868,33 +1930,30 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
                 p.seds_len[seg] = (u64)(info & 0xffu) + p.tok_total;
                 p.segmeta[seg] = META_REC | META_INLINE | ((info >> 30) & 1u ? META_KIND4 : 0) | slot;
                 work_wide = (info >> 30) & 1u;
-                break;
+                done = true;
             }
         }
-        u64 cm = 0;                                       // 0: generic kernels
-        const u64 ncol = b - a;
-        if (ncol <= 64) {
-            const u64 s0 = mv.slot(a);
-            bool pure = true, contig = true;
-            for (u64 c = a + 1; c < b; c++) {
-                pure = pure && mv.vbit(c);
-                if (pure) contig = contig && mv.slot(c) == s0 + (c - a);
+        if (!done) {
+            u64 cm = 0;                                       // 0: generic kernels
+            const u64 ncol = b - a;
+            if (ncol <= 64) {
+                const u64 s0 = mv.slot(a);
+                bool pure = true, contig = true;
+                for (u64 c = a + 1; c < b; c++) {
+                    pure = pure && mv.vbit(c);
+                    if (pure) contig = contig && mv.slot(c) == s0 + (c - a);
+                }
+                if (pure) cm = (ncol << 48) | s0 | (contig ? 0 : CNT_SCATTER);
+                else cm = (ncol << 48) | s0 | CNT_MIXED;      // context merge: common columns inside (every row has the reference byte there)
             }
-            if (pure) cm = (ncol << 48) | s0 | (contig ? 0 : CNT_SCATTER);
-            else cm = (ncol << 48) | s0 | CNT_MIXED;      // context merge: common columns inside (every row has the reference byte there)
+            if (!cm) p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;        // too wide or mixed columns
+            p.segmeta[seg] = 0;                               // k_seg_group fills it in
+            work_cm = cm;
         }
-        if (!cm) p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg;        // too wide or mixed columns
-        p.segmeta[seg] = 0;                               // k_seg_group fills it in
-        work_vi = vi; work_cm = cm;
-        } while (false);
-        if (seg < nseg && mv.vbit(p.seg_start[seg])) {
-            const u64 vi = (seg - p0) >> 1;
-            // light list: up to ten pure variant columns; heavy list: 11..64 columns or common columns inside (the two
-            // grouping kernels run side by side)
-            const bool heavy = work_cm && ((work_cm & CNT_MIXED) || ((work_cm >> 48) & 0xffu) > 10u);
-            p.cnt_meta[vi] = work_cm; p.cnt_flag[vi] = work_cm && !heavy ? 1 : 0; p.heavy_flag[vi] = heavy ? 1 : 0;
-            p.wide_flag[vi] = work_wide;
-        }
+        // light list: up to ten pure variant columns; heavy list: 11..64 columns or common columns inside
+        const bool heavy = work_cm && ((work_cm & CNT_MIXED) || ((work_cm >> 48) & 0xffu) > 10u);
+        p.cnt_meta[vi] = work_cm; p.cnt_flag[vi] = work_cm && !heavy ? 1 : 0; p.heavy_flag[vi] = heavy ? 1 : 0;
+        p.wide_flag[vi] = work_wide;
     }
 }
 
@@ -2290,13 +2349,13 @@ __device__ __forceinline__ u32 lane_read(u32 v, u32 src_lane)       // v of lane
 //   place the tokens (rows that are not placed use a dummy cursor: no branches, all 16 atomics in flight together).
 //   Every string's region of `stage` is padded so that its 4-byte tokens are dword-aligned; the regions are copied
 //   out one by one (16-byte LDS reads, unaligned 16-byte global stores, byte stores for the ragged ends).
-template <int BITS, bool HAS5, class Lds, class PreFlush>
+template <int BITS, bool HAS5, int KMAX, class Lds, class PreFlush>
 __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, bool v0, bool v1, u32 k, u32 S, u32 lane,
                                         const u32 (&tokc)[16], u32 htok0, u32 htok1, Lds& L, uint8_t* gseds,
                                         PreFlush pre_flush)
 {
-    constexpr u32 K = BITS == 2 ? 4u : 16u;        // table rows in use (row K: dummies)
-    constexpr int NQ = BITS == 2 ? 1 : 4;          // quartets of strings
+    constexpr u32 K = BITS == 2 ? 4u : (u32)KMAX;  // table rows in use (row K: dummies); 4-bit ids: 8 or 16 strings at most
+    constexpr int NQ = BITS == 2 ? 1 : KMAX / 4;   // quartets of strings
     const u32 sbase = (u32)(uintptr_t)L.stage;     // LDS byte address (low half of the flat address)
     const u32 tl0 = lane < 9u ? 2u : 3u, tl1 = lane < 35u ? 3u : 4u;       // ids 1-9 | 10-64 and 65-99 | 100-128
     u32 ex0 = 0, ex1 = 0;            // bytes of this lane's string in front of this lane's token, inside the block
@@ -2319,7 +2378,7 @@ __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, 
     const u32 m5 = HAS5 ? (first5 >= 16u ? 0u : (0xffffu << first5) & 0xffffu) : 0u;
     // ---- rows 128..: bytes of every string among this lane's rows, prefix over the lanes, totals
     u32 pre[K];                      // bytes of string g in the lanes before this one (rows >= 128)
-    u32 bbt[BITS == 2 ? 2 : 8];      // totals, two 16-bit fields per dword (uniform)
+    u32 bbt[BITS == 2 ? 2 : KMAX / 2];   // totals, two 16-bit fields per dword (uniform)
     if (BITS == 2) {
         // spread the row masks to the 2-bit fields
         auto spread = [](u32 m) -> u32 { m = (m | (m << 8)) & 0x00ff00ffu; m = (m | (m << 4)) & 0x0f0f0f0fu;
@@ -2343,19 +2402,19 @@ __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, 
         bbt[1] = (u32)__builtin_amdgcn_readlane((int)s23, 63);
     } else {
 #pragma unroll
-        for (int g = 0; g < 16; g++) L.tab[g * 64 + lane] = 0;
+        for (int g = 0; g < (int)K; g++) L.tab[g * 64 + lane] = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const bool act = (am & (1u << j)) != 0;
             const u32 g = ((j < 8 ? x0 : x1) >> (4u * (j & 7))) & 15u;
             const u32 inc = act ? ((m5 >> j) & 1u ? 5u : 4u) : 0u;
-            atomicAdd(&L.tab[(act ? g : 16u) * 64u + lane], inc);
+            atomicAdd(&L.tab[(act ? g : K) * 64u + lane], inc);
         }
-        u32 c[16];
+        u32 c[K];
 #pragma unroll
-        for (int g = 0; g < 16; g++) c[g] = L.tab[g * 64 + lane];
+        for (int g = 0; g < (int)K; g++) c[g] = L.tab[g * 64 + lane];
 #pragma unroll
-        for (int h = 0; h < 8; h++) {
+        for (int h = 0; h < (int)K / 2; h++) {
             bbt[h] = 0; pre[2 * h] = 0; pre[2 * h + 1] = 0;
             if ((u32)h * 2u < k) {
                 const u32 pk = c[2 * h] | (c[2 * h + 1] << 16);
@@ -2377,7 +2436,7 @@ __device__ __forceinline__ u32 emit_ids(u32 x0, u32 x1, u32 am, u32 g0, u32 g1, 
         hb = ((t0 >> ((lane & 3u) * 8u)) & 0xffu) + ((t1 >> ((lane & 3u) * 8u)) & 0xffu);
         u32 tt = bbt[0];
 #pragma unroll
-        for (int h = 1; h < (BITS == 2 ? 2 : 8); h++) tt = (lane >> 1) == (u32)h ? bbt[h] : tt;
+        for (int h = 1; h < (BITS == 2 ? 2 : (int)K / 2); h++) tt = (lane >> 1) == (u32)h ? bbt[h] : tt;
         bb = (tt >> ((lane & 1u) * 16u)) & 0xffffu;
     }
     const u32 sz = lane < k ? 1u + hb + bb : 0u;                 // '{' + tokens; the last ',' becomes '}'
@@ -2741,17 +2800,24 @@ __global__ void __launch_bounds__(256, 5) k_emit_fast2(FastParams p)
 }
 
 // WIDE false: the segments of up to four strings (2-bit group ids); true: those of 5..64 strings
-template <bool HAS5, bool WIDE>
-__global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
+// KMAX (WIDE): 8 - the segments of 5..8 strings, at four waves per SIMD; 16 - those of 9..64 strings (17..64 sixteen at a
+// time).  Both walk the one work list and skip what is the other's.
+#if defined(EDSX_EXPERIMENTS) && defined(EDSX_WIDE_SINGLE)
+constexpr bool WIDE_SINGLE = true;                      // one wide launch takes every segment of 5..64 strings
+#else
+constexpr bool WIDE_SINGLE = false;
+#endif
+template <bool HAS5, bool WIDE, int KMAX = 16>
+__global__ void __launch_bounds__(256, WIDE ? (KMAX == 8 ? 4 : 2) : 5) k_emit_fast(FastParams p)
 {
-    using WaveLds = EmitWaveLdsT<WIDE ? 17 : 5>;
+    using WaveLds = EmitWaveLdsT<WIDE ? KMAX + 1 : 5>;
     __shared__ WaveLds lds_all[4];
     const MsaView& mv = p.mv;
     if (mv.hdr->status) return;
     const u32 lane = threadIdx.x & 63, wv = uniform32(threadIdx.x >> 6);
     WaveLds& L = lds_all[wv];
     const u32 S = mv.S;
-    L.tab[(WIDE ? 16 : 4) * 64 + lane] = (u32)EM_STAGE + 4u * lane;     // dummy cursors (never advanced: they are added 0)
+    L.tab[(WIDE ? KMAX : 4) * 64 + lane] = (u32)EM_STAGE + 4u * lane;   // dummy cursors (never advanced: they are added 0)
     // lane constants: tokens "ddd," of this lane's rows 16*lane .. +15 (ids 100..999; "dddd" from 1000), of rows
     // `lane` and `64 + lane`, and which of this lane's rows are placed by the owning lane (rows >= 128)
     u32 tokc[16];
@@ -2819,9 +2885,10 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
         const EmitRec rc = load_rec(meta);
         const EmitRec rc_n = rc;
         const u64 meta_v = 0, qoff_v = 0, eoff_v = 0;
-        const bool fast = (meta & META_REC) != 0 && ((meta & (META_KIND4 | META_KIND8)) != 0) == WIDE;
         const u32 hdr0 = uniform32(rc.hv);
         const u32 k = hdr0 & 0xffu, textlen = (hdr0 >> 8) & 0xffu, ncol = (hdr0 >> 16) & 0xffu;
+        const bool fast = (meta & META_REC) != 0 && ((meta & (META_KIND4 | META_KIND8)) != 0) == WIDE &&
+                          (!WIDE || WIDE_SINGLE || (KMAX == 8) == (k <= 8u));
         uint8_t* gseds = p.seds + qoff;
         // the wait for the prefetched record: called right before this segment's id lists are stored (everything
         // before that point that reads global memory is older than the prefetch or was waited for already)
@@ -2879,7 +2946,7 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
                     }
                 }
             }
-            if (WIDE && (meta & META_KIND8)) {
+            if (WIDE && (meta & META_KIND8)) { if constexpr (KMAX == 16) {
                 // 17..64 strings: sixteen at a time (strings 16t .. 16t+15 of the rows whose id is in that range)
                 const u32 f = lane & 15u, src = lane >> 4;
                 auto head_gid = [&](u32 sl) -> u32 {        // (all four reads by all lanes: ds_bpermute takes data from active lanes only)
@@ -2896,18 +2963,18 @@ __global__ void __launch_bounds__(256, WIDE ? 2 : 5) k_emit_fast(FastParams p)
                     const u32 am = (eq_byte4((rc.x.x >> 4) & 0x0f0f0f0fu, tt) | (eq_byte4((rc.x.y >> 4) & 0x0f0f0f0fu, tt) << 4) |
                                     (eq_byte4((rc.x.z >> 4) & 0x0f0f0f0fu, tt) << 8) | (eq_byte4((rc.x.w >> 4) & 0x0f0f0f0fu, tt) << 12)) & amv;
                     const u32 kt = k - t * 16u < 16u ? k - t * 16u : 16u;
-                    run += emit_ids<WIDE ? 4 : 2, HAS5>(xx.x, xx.y, am, G0 & 15u, G1 & 15u, hv0 && (G0 >> 4) == t, hv1 && (G1 >> 4) == t,
+                    run += emit_ids<WIDE ? 4 : 2, HAS5, 16>(xx.x, xx.y, am, G0 & 15u, G1 & 15u, hv0 && (G0 >> 4) == t, hv1 && (G1 >> 4) == t,
                                              kt, S, lane, tokc, htok0, htok1, L, gseds + run, pre_flush);
                 }
-            } else if (WIDE) {
+            } } else if (WIDE) {
                 const u32 f = lane & 15u, src = lane >> 4;
                 const u32 a0 = lane_read(rc.x.x, src), a1 = lane_read(rc.x.y, src), b0 = lane_read(rc.x.x, src + 4u), b1 = lane_read(rc.x.y, src + 4u);
                 const u32 g0 = (((f & 8u) ? a1 : a0) >> (4u * (f & 7u))) & 15u, g1 = (((f & 8u) ? b1 : b0) >> (4u * (f & 7u))) & 15u;
-                emit_ids<WIDE ? 4 : 2, HAS5>(rc.x.x, rc.x.y, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush);
+                emit_ids<WIDE ? 4 : 2, HAS5, KMAX>(rc.x.x, rc.x.y, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush);
             } else {
                 const u32 f = lane & 15u, src = lane >> 4;
                 const u32 g0 = (lane_read(rc.x.x, src) >> (2u * f)) & 3u, g1 = (lane_read(rc.x.x, src + 4u) >> (2u * f)) & 3u;
-                emit_ids<WIDE ? 2 : 2, HAS5>(rc.x.x, 0u, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush);
+                emit_ids<WIDE ? 2 : 2, HAS5, 4>(rc.x.x, 0u, amv, g0, g1, hv0, hv1, k, S, lane, tokc, htok0, htok1, L, gseds, pre_flush);
             }
         } else pre_flush();
     }
@@ -2995,16 +3062,16 @@ static const char* status_message(u64 st)
 {
     if (st & ST_NOT_FASTA) return "Invalid MSA: expected a FASTA header line starting with '>'";
     if (st & ST_FEW_ROWS) return "Invalid MSA: at least two sequences are required";
-    if (st & ST_TOO_MANY_ROWS) return "MSA has more sequences than this build supports (8192)";
+    if (st & ST_TOO_MANY_ROWS) return "MSA has more sequences than this build supports (9999999)";
     if (st & ST_NEWLINE_IN_DATA) return "Invalid MSA: rows must have equal length and a uniform line width";
     if (st & ST_LAYOUT) return "Invalid MSA: rows must have equal length and a uniform line width";
     return "MSA transform failed";
 }
 
-template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW, bool ROWS64 = false>
+template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW, bool ROWS64 = false, bool BIG = false>
 static void launch_k1(const K1Params& p, size_t lds, hipStream_t st)
 {
-    auto kern = k_scan_extract<T, RPT, HOLD, LANEROWS, MINW, ROWS64>;
+    auto kern = k_scan_extract<T, RPT, HOLD, LANEROWS, MINW, ROWS64, BIG>;
     EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)p.ntiles), dim3(T), lds, st, p);
@@ -3019,27 +3086,35 @@ void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t s
     if (n == 0) throw FormatError("Invalid MSA: empty input");
 
     hdr_.ensure(sizeof(MsaHdr));
-    rows_.ensure(sizeof(u64) * ROW_CAP);
     MsaHdr* dh = hdr_.as<MsaHdr>();
-    EDSX_HIP(hipMemsetAsync(dh, 0, sizeof(MsaHdr), st));
-
-    // ---- K0: geometry + row index (one host sync: everything below is sized from it)
-    TIMED("k_find_hdr_end", st, hipLaunchKernelGGL(k_find_hdr_end, dim3(1), dim3(64), 0, st, d_msa, (u64)n, dh));
-    TIMED("k_find_row0", st, hipLaunchKernelGGL(k_find_row0, dim3(512), dim3(1024), 0, st, d_msa, (u64)n, dh));
-    idx_tmp_.ensure(2 * sizeof(u64) * ROW_CAP);
-    TIMED("k_index_spec", st, hipLaunchKernelGGL(k_index_spec, dim3(512), dim3(256), 0, st, d_msa, (u64)n, dh,
-                                                 idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + ROW_CAP, (u64)ROW_CAP));
-    TIMED("k_index_check", st, hipLaunchKernelGGL(k_index_check, dim3(1), dim3(1024), 0, st, d_msa, (u64)n, dh,
-                                                  idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + ROW_CAP, rows_.as<u64>(), (u64)ROW_CAP));
-    TIMED("k_index_rows", st, hipLaunchKernelGGL(k_index_rows, dim3(1), dim3(64), 0, st, d_msa, (u64)n, dh,
-                                                 rows_.as<u64>(), (u64)ROW_CAP));
-    EDSX_HIP(hipMemcpyAsync(&h_, dh, sizeof(MsaHdr), hipMemcpyDeviceToHost, st));
-    EDSX_HIP(hipStreamSynchronize(st));
+    // ---- K0: geometry + row index (one host sync: everything below is sized from it).  The row table starts with room
+    // for ROW_CAP rows; an alignment with more rows is indexed again with the table sized from its first row's length.
+    u64 row_cap = ROW_CAP;
+    for (int attempt = 0;; attempt++) {
+        rows_.ensure(sizeof(u64) * (row_cap + ROW_PAD));
+        idx_tmp_.ensure(2 * sizeof(u64) * row_cap);
+        EDSX_HIP(hipMemsetAsync(dh, 0, sizeof(MsaHdr), st));
+        TIMED("k_find_hdr_end", st, hipLaunchKernelGGL(k_find_hdr_end, dim3(1), dim3(64), 0, st, d_msa, (u64)n, dh));
+        TIMED("k_find_row0", st, hipLaunchKernelGGL(k_find_row0, dim3(512), dim3(1024), 0, st, d_msa, (u64)n, dh));
+        TIMED("k_index_spec", st, hipLaunchKernelGGL(k_index_spec, dim3(512), dim3(256), 0, st, d_msa, (u64)n, dh,
+                                                     idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + row_cap, row_cap));
+        TIMED("k_index_check", st, hipLaunchKernelGGL(k_index_check, dim3(1), dim3(1024), 0, st, d_msa, (u64)n, dh,
+                                                      idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + row_cap, rows_.as<u64>(), row_cap));
+        TIMED("k_index_rows", st, hipLaunchKernelGGL(k_index_rows, dim3(1), dim3(64), 0, st, d_msa, (u64)n, dh,
+                                                     rows_.as<u64>(), row_cap));
+        EDSX_HIP(hipMemcpyAsync(&h_, dh, sizeof(MsaHdr), hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        if (attempt == 0 && h_.status == ST_TOO_MANY_ROWS) {
+            const u64 most = n / (h_.Draw + 3) + 2;            // ">\n" + the row + "\n" at least
+            if (most > row_cap && row_cap <= MAX_ROWS) { row_cap = std::min<u64>(most, MAX_ROWS + 1); clear_timers(); continue; }
+        }
+        break;
+    }
     if (h_.status & ST_TOO_MANY_ROWS) throw LimitError(status_message(ST_TOO_MANY_ROWS));
     if (h_.status) throw FormatError(status_message(h_.status));
     if (h_.S > MAX_ROWS) throw LimitError(status_message(ST_TOO_MANY_ROWS));
     {   // padding for the column scan's 16-row loads (at most 256 threads x 16 rows past the last one)
-        const u64 padded = std::min<u64>(ROW_CAP, (h_.S + 15) / 16 * 16 + 4096);
+        const u64 padded = std::min<u64>(row_cap + ROW_PAD, (h_.S + 15) / 16 * 16 + 4096);
         hipLaunchKernelGGL(k_pad_rows, dim3(4), dim3(256), 0, st, rows_.as<u64>(), h_.S, padded);
     }
 
@@ -3114,16 +3189,15 @@ void MsaPipeline::plan_body(hipStream_t st)
     const u64 ntiles = (Draw + W - 1) / W;
     // 40 KB of column image (39 columns of 1000 rows; denser tiles take the batched path) leave room for a third
     // workgroup per CU to start while the two resident ones finish their grouping tails (-1.7 % on the scan)
-    const size_t colbuf_bytes = (size_t)S * 8 <= 40 * 1024 ? 40 * 1024 : 64 * 1024;
+    big_ = S > LDS_ROWS;                                  // row tables / column image in HBM instead of LDS
+    const size_t colbuf_bytes = big_ ? 64 : (size_t)S * 8 <= 40 * 1024 ? 40 * 1024 : 64 * 1024;
     if (ntiles > 0x7fffffffull) throw FormatError("MSA too large for one launch");
-    if (colbuf_bytes < (size_t)S * 8) throw LimitError(status_message(ST_TOO_MANY_ROWS));
 
     K1Params kp;
     kp.file = d_msa; kp.row_start = rows_.as<u64>(); kp.hdr = dh;
     kp.Vraw = vraw_.as<u64>(); kp.word_slot = wslot_.as<u64>(); kp.vc = vc_.as<uint8_t>();
     kp.vc_cap_cols = vc_cap_cols_; kp.Draw = Draw; kp.lw = lw; kp.S = (u32)S; kp.Spad = Spad;
     kp.cpr_log2 = cpr_log2; kp.cap_cols = (u32)(colbuf_bytes / Spad); kp.ntiles = ntiles;
-    if (kp.cap_cols == 0) throw LimitError(status_message(ST_TOO_MANY_ROWS));
     const bool lane_rows = hold && RPT == 16;             // thread rows = 16 consecutive rows = 16 consecutive vc bytes
     // fused grouping: context length 0 (segments = runs), one-line rows (raw position = column), wave-per-segment code
     fuse_ = l == 0 && lw == 0 && S <= 1024 && lane_rows;
@@ -3141,6 +3215,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     if (lane_rows && fuse_ && S <= 64) launch_k1<512, 16, true, true, 4, true>(kp, colbuf_bytes, st);   // one row per lane in the fused grouping
     else if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
     else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
+    else if (big_) launch_k1<512, 16, false, false, 4, false, true>(kp, colbuf_bytes, st);
     else launch_k1<512, 16, false, false, 4>(kp, colbuf_bytes, st);
     launch_timer_end(st);
 
@@ -3185,7 +3260,15 @@ void MsaPipeline::plan_body(hipStream_t st)
     seg_lds_ = (seg_lds_ + 15) & ~(size_t)15;
     stage_off_ = 0;
     stage_cols_ = 0;
-    {                                                     // as many columns of a segment as fit beside that (<= STAGE_COLS)
+    seg_scratch_stride_ = 0;
+    if (big_) {
+        // the generic kernels' row tables (20 B per row) and the emitter's walk tables: a slice of HBM per workgroup;
+        // as many workgroups as 8 GiB of it allow (32 .. 512)
+        seg_lds_ = 64;
+        seg_scratch_stride_ = (((SegLdsT<true>::bytes((u32)S) + 15) & ~(size_t)15) + walk_table_bytes<true>((u32)S) + 255) & ~(size_t)255;
+        big_grid_ = (unsigned)std::max<u64>(32, std::min<u64>(512, (8ull << 30) / seg_scratch_stride_));
+        seg_scratch_.ensure((size_t)big_grid_ * seg_scratch_stride_);
+    } else {                                                     // as many columns of a segment as fit beside that (<= STAGE_COLS)
         const size_t budget = (size_t)150 * 1024;
         const size_t maps = 2 * (size_t)STAGE_WMAX + 16;     // column map + reference bytes of the common columns
         constexpr size_t GEN_MINCOLS = 24;
@@ -3207,10 +3290,10 @@ void MsaPipeline::plan_body(hipStream_t st)
     }
 
     // grouping cache of the generic kernels (count -> emit): two regions (one per work list; without lists: both)
-    gc_stride_ = gcache_stride_of((u32)S);
+    gc_stride_ = gcache_stride_of((u32)S, big_);
     // (with the wave-per-segment kernels in front - up to 1024 rows - only the few segments on their slow lists come here:
     // 256 MiB per list; items beyond the cache are simply grouped again by the emitter)
-    gc_region_ = (size_t)std::min<u64>((u64)(S <= 1024 ? 256u : 1024u) << 20, (L / 2 + 4) * (u64)gc_stride_);
+    gc_region_ = (size_t)std::min<u64>(std::max<u64>((u64)(S <= 1024 ? 256u : 1024u) << 20, 4 * gc_stride_), (L / 2 + 4) * (u64)gc_stride_);
     gc_region_ = gc_region_ / gc_stride_ * gc_stride_;
     gcache_.ensure(2 * gc_region_ + 16);
 
@@ -3223,7 +3306,8 @@ void MsaPipeline::plan_body(hipStream_t st)
     long_list_.ensure(8 * (L / LONG_COMMON + 4));             // the long common segments
     sp.long_list = long_list_.as<u64>(); sp.long_count = &dh->long_n;
     EDSX_HIP(hipMemsetAsync(&dh->long_n, 0, sizeof(u64), st));
-    EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_count),
+    sp.scratch = seg_scratch_.as<uint8_t>(); sp.scratch_stride = seg_scratch_stride_;
+    EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_count<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     if (fast_) {
         segmeta_.ensure(8 * (L + 2));
@@ -3271,12 +3355,13 @@ void MsaPipeline::plan_body(hipStream_t st)
                   reinterpret_cast<const void*>(k_seg_group<true>), 256, 0)), dim3(256), 0, st, fp_, fp_.heavy2_vi, fp_.heavy2_cm, &dh->heavy2_n));
         sp.gcache_stride = gc_stride_; sp.gcache_cap = gc_region_ / gc_stride_;
         sp.list = fp_.slow_list; sp.list_n = fp_.slow_count; sp.gcache = gcache_.as<uint8_t>();
-        TIMED("k_seg_count_slow", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
+        TIMED("k_seg_count_slow", st, hipLaunchKernelGGL(k_seg_count<false>, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
         sp.list = fp_.slow_list2; sp.list_n = fp_.slow_count2; sp.gcache = gcache_.as<uint8_t>() + gc_region_;
-        TIMED("k_seg_count_slow2", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
+        TIMED("k_seg_count_slow2", st, hipLaunchKernelGGL(k_seg_count<false>, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
     } else {
         sp.gcache_stride = gc_stride_; sp.gcache_cap = 2 * gc_region_ / gc_stride_; sp.gcache = gcache_.as<uint8_t>();
-        TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
+        if (big_) TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count<true>, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
+        else TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count<false>, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
     }
     {   // text offsets of both outputs: one pass
         ScanSet<2> ss{{eds_len_.as<u64>(), seds_len_.as<u64>()}, {eds_len_.as<u64>(), seds_len_.as<u64>()}, {&dh->E, &dh->Q}};
@@ -3302,6 +3387,7 @@ unsigned MsaPipeline::persistent_grid(const void* kern, int threads, size_t dyn_
 unsigned MsaPipeline::seg_grid() const
 {
     // persistent workgroups striding over the segments; several per CU to hide latency
+    if (big_) return big_grid_;
     size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / std::max<size_t>(seg_lds_, 1)));
     return (unsigned)(256 * per_cu);
 }
@@ -3395,7 +3481,8 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
     ep.nwords = h_.nwords;
     ep.list = nullptr; ep.list_n = nullptr;
     ep.stage_cols = stage_cols_; ep.stage_off = stage_off_;
-    EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_emit_variant),
+    ep.scratch = seg_scratch_.as<uint8_t>(); ep.scratch_stride = seg_scratch_stride_;
+    EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_emit_variant<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_));
     auto launch_common = [&](hipStream_t s) {                 // the common segments: "{" reference text "}" and "{0}"
         TIMED("k_emit_common_seg", s, hipLaunchKernelGGL(k_emit_common_seg, dim3(4096), dim3(256), 0, s, mv_, seg_start_p_, nseg_p_,
@@ -3417,21 +3504,29 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
         launch_emit(k_emit_fast2, "k_emit_fast");
         ensure_side_streams();
         hipStream_t s1 = side_[0], s2 = side_[1];
+#if defined(EDSX_EXPERIMENTS) && defined(EDSX_TAIL_SERIAL)
+        s1 = st; s2 = st;                                   // every kernel alone: what each costs by itself
+#endif
         EDSX_HIP(hipEventRecord(side_ev_[0], st));
         EDSX_HIP(hipStreamWaitEvent(s1, side_ev_[0], 0));
         EDSX_HIP(hipStreamWaitEvent(s2, side_ev_[0], 0));
         {
-            auto launch_wide = [&](auto kern) {
-                TIMED("k_emit_fast_wide", st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
-                                                                 dim3(256), 0, st, fp));
+            auto launch_wide = [&](auto kern, const char* name) {
+                TIMED(name, st, hipLaunchKernelGGL(kern, dim3(persistent_grid(reinterpret_cast<const void*>(kern), 256, 0)),
+                                                   dim3(256), 0, st, fp));
             };
-            if (h_.S >= 1000) launch_wide(k_emit_fast<true, true>);      // ids of five bytes exist
-            else launch_wide(k_emit_fast<false, true>);
+            if (h_.S >= 1000) {                                          // ids of five bytes exist
+                if (!WIDE_SINGLE) launch_wide(k_emit_fast<true, true, 8>, "k_emit_fast_wide8");
+                launch_wide(k_emit_fast<true, true, 16>, "k_emit_fast_wide16");
+            } else {
+                if (!WIDE_SINGLE) launch_wide(k_emit_fast<false, true, 8>, "k_emit_fast_wide8");
+                launch_wide(k_emit_fast<false, true, 16>, "k_emit_fast_wide16");
+            }
         }
         ep.gcache_stride = gc_stride_; ep.gcache_cap = gc_region_ / gc_stride_;
         ep.list = fp_.slow_list; ep.list_n = fp_.slow_count; ep.gcache = gcache_.as<uint8_t>();
         ep.list2 = fp_.slow_list2; ep.list2_n = fp_.slow_count2; ep.gcache2 = gcache_.as<uint8_t>() + gc_region_;
-        TIMED("k_emit_variant_slow", s2, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
+        TIMED("k_emit_variant_slow", s2, hipLaunchKernelGGL(k_emit_variant<false>, dim3(seg_grid()), dim3(GT), seg_lds_, s2, ep));
         launch_common(s1);
         EDSX_HIP(hipEventRecord(side_ev_[1], s1));
         EDSX_HIP(hipEventRecord(side_ev_[2], s2));
@@ -3440,7 +3535,8 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
     } else {
         launch_common(st);
         ep.gcache_stride = gc_stride_; ep.gcache_cap = 2 * gc_region_ / gc_stride_; ep.gcache = gcache_.as<uint8_t>();
-        TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+        if (big_) TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant<true>, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
+        else TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant<false>, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
     }
     EDSX_HIP(hipGetLastError());
 }

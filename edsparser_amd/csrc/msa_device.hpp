@@ -142,8 +142,10 @@ struct FastParams {
 
 class MsaPipeline {
 public:
-    static constexpr u64 MAX_ROWS = 8192;      // LDS budget of the grouping kernels (18 B / row)
-    static constexpr u64 ROW_CAP = 65536;
+    static constexpr u64 MAX_ROWS = 9999999;   // sequence ids of up to seven digits (an id + ',' is one 8-byte token)
+    static constexpr u64 LDS_ROWS = 8192;      // LDS budget of the generic kernels (18 B / row); more rows: tables in HBM scratch
+    static constexpr u64 ROW_CAP = 65536;      // first size of the row table (grown once when an alignment has more rows)
+    static constexpr u64 ROW_PAD = 4200;       // copies of the last row behind it (16-row loads of the column scan)
 
     ~MsaPipeline();
     void plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t st, uint64_t* eds_bytes, uint64_t* seds_bytes);
@@ -191,7 +193,10 @@ private:
     u32 stage_off_ = 0, stage_cols_ = 0;   // generic kernels: column staging area in their LDS (offset, capacity; 0: none)
     bool fast_ = false, fuse_ = false;
     u32 recf_stride_ = 0, recf_gid_ = 0;
-    u32 gc_stride_ = 0;                      // grouping cache of the generic kernels: entry size, bytes per region
+    bool big_ = false;                       // more than LDS_ROWS rows
+    unsigned big_grid_ = 0;
+    DevBuf seg_scratch_; size_t seg_scratch_stride_ = 0;      // ... their row tables: one slice per workgroup
+    u64 gc_stride_ = 0;                      // grouping cache of the generic kernels: entry size, bytes per region
     size_t gc_region_ = 0;
     FastParams fp_{};
     int cus_ = 0;

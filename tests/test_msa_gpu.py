@@ -63,16 +63,38 @@ def test_format_errors(ctx):
 
 
 def test_row_limit_is_a_build_limit_not_a_format_error(ctx):
-    """More than 8192 sequences: a limit of this build (LDS budget of the grouping kernels), reported as
-    EDSX_ERR_BUILD_FAILED (4) with its own text; 8192 rows still transform and equal the oracle."""
+    """The row limit of the build is the width of a sequence id in the .seds text (seven digits + ',' = one 8-byte
+    token): 10 000 000 sequences are reported as EDSX_ERR_BUILD_FAILED (4) with their own text, not as a format error."""
     import edsparser_amd
-    rows = [b"ACGTACGTAC" if i % 3 else b"ACGTTCGTAC" for i in range(8193)]
-    big = b"".join(b">s%d\n" % i + r + b"\n" for i, r in enumerate(rows))
+    big = b">\nA\n" * 10_000_000
     with pytest.raises(edsparser_amd.EdsxError) as ei:
         ctx.msa_transform(big, 0)
     assert ei.value.code == 4 and "more sequences than this build supports" in ei.value.message
-    ok = b"".join(b">s%d\n" % i + r + b"\n" for i, r in enumerate(rows[:8192]))
-    assert ctx.msa_transform(ok, 0) == o.msa(ok, 0)
+
+
+@pytest.mark.parametrize("S,L", [(8193, 400), (12000, 300), (70001, 60)])
+def test_more_rows_than_the_lds_holds(ctx, S, L):
+    """More than 8192 sequences: the generic kernels keep their row tables in HBM scratch (32-bit group ids), the column
+    scan reads row starts from HBM and writes variant bytes straight to vc, the row table is grown past its first 65536
+    entries.  One-line and wrapped rows, l = 0 and an l-EDS, against the oracle."""
+    rng = random.Random(77 + S)
+    for lw in (None, 61):
+        msa = random_msa(rng, S=S, L=L, lw=lw, p_var=0.06)
+        for l in (0, 3):
+            got = ctx.msa_transform(msa, l)
+            want = o.msa(msa, l)
+            assert got == want, (S, lw, l)
+
+
+def test_more_than_65535_strings_in_one_segment(ctx):
+    """70 000 rows of ten random letters: one variant segment with more distinct strings than a 16-bit group id counts."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    S, L = 70_000, 10
+    cells = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(S, L))]
+    msa = b"".join(b">r%d\n" % i + cells[i].tobytes() + b"\n" for i in range(S))
+    assert len({cells[i].tobytes() for i in range(S)}) > 65535
+    assert ctx.msa_transform(msa, 0) == o.msa(msa, 0)
 
 
 def test_trailing_blank_lines_tolerated(ctx):
