@@ -73,6 +73,9 @@ def load_library():
     lib.edsx_buf_free.argtypes = [P(_Buf)]
     lib.edsx_msa_transform.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
                                        P(_Buf), P(_Buf)]
+    lib.edsx_msa_last_batches.argtypes = [ctypes.c_void_p]
+    lib.edsx_msa_transform_batched.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int,
+                                               P(_Buf), P(_Buf), P(ctypes.c_int)]
     lib.edsx_leds_merge.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                     ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, P(_Buf), P(_Buf)]
     lib.edsx_vcf_transform.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
@@ -222,6 +225,25 @@ class Context:
         self._check(self._lib.edsx_msa_transform(self._h, ptr, n, context_len, ctypes.byref(e), ctypes.byref(s)))
         del keep
         return self._take(e), self._take(s)
+
+    def msa_last_batches(self):
+        return int(self._lib.edsx_msa_last_batches(self._h))
+
+    def msa_transform_batched(self, msa, context_len=0, batches=2):
+        """The same in `batches` column batches, one after the other on this GPU (bounded working set).  Returns
+        (eds, seds, batches taken) - 1 when the input is not cut."""
+        e, s = _Buf(), _Buf()
+        used = ctypes.c_int(0)
+        if isinstance(msa, bytes):
+            ptr, n, keep = msa, len(msa), msa
+        else:
+            import numpy as np
+            keep = np.frombuffer(msa, dtype=np.uint8)
+            ptr, n = ctypes.c_void_p(keep.ctypes.data), int(keep.size)
+        self._check(self._lib.edsx_msa_transform_batched(self._h, ptr, n, context_len, batches, ctypes.byref(e), ctypes.byref(s),
+                                                         ctypes.byref(used)))
+        del keep
+        return self._take(e), self._take(s), used.value
 
     def leds_merge(self, eds, seds=None, context_len=1, compact=True):
         o, so = _Buf(), _Buf()

@@ -13,6 +13,11 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libedsx.so")
 SOURCES = ["msa_device.hip", "merge_device.hip", "vcf_device.hip", "synth.hip", "genrandom.hip", "genvcf.hip", "multi_gpu.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# A second library for the tests only: the merge's final-text kernel with a 256-entry LDS stack and a 2-entry register stack
+# in its serial walk, so that ordinary inputs take the overflow -> serial walk -> HBM spill-stack path that otherwise needs
+# merge trees deeper than 96 (tests/test_merge_gpu.py::test_deep_tree_fallback_paths).  Never loaded by the product.
+TEST_LIB = os.path.join(HERE, "libedsx_smallstacks.so")
+TEST_FLAGS = {"merge_device.hip": ["-DEDSX_EXPERIMENTS", "-DEDSX_FW_STACK=256", "-DEDSX_FIN_STACK=2"]}
 
 
 def _headers():
@@ -60,6 +65,14 @@ def build(force=False, verbose=False):
             list(ex.map(lambda j: _compile(j[0], j[1], j[2], verbose), jobs))
     if force or _newer(LIB, objs):
         _link(objs, LIB, verbose)
+    tobjs = list(objs)
+    for name, extra in TEST_FLAGS.items():
+        src, obj = os.path.join(CSRC, name), os.path.join(OBJ, name.replace(".hip", ".smallstacks.o"))
+        tobjs[tobjs.index(os.path.join(OBJ, name.replace(".hip", ".o")))] = obj
+        if force or _newer(obj, [src] + hdrs):
+            _compile(src, obj, extra, verbose)
+    if force or _newer(TEST_LIB, tobjs):
+        _link(tobjs, TEST_LIB, verbose)
     return LIB
 
 

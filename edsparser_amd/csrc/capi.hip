@@ -28,6 +28,9 @@ struct edsx_ctx {
     GenVcfPipeline genvcf;
     DevBuf d_in, d_eds, d_seds, synth_desc;
     std::vector<uint8_t> host_tmp;
+    std::unique_ptr<MsaPipeline> mini;       // column batches: the boundary segments are recomputed through a second pipeline
+    DevBuf d_mini;
+    int last_batches = 0;                    // of the last edsx_msa_transform / _batched: 1 = one piece
 };
 
 namespace {
@@ -53,6 +56,54 @@ void take(edsx_buf* b, size_t n)
 {
     b->data = HostBytes::alloc(n);
     b->size = n;
+}
+
+// everything the MSA entry points hold on the device goes back to the allocator
+void release_msa_buffers(edsx_ctx* ctx)
+{
+    ctx->d_in.release(); ctx->d_eds.release(); ctx->d_seds.release(); ctx->d_mini.release();
+    ctx->msa.~MsaPipeline();
+    new (&ctx->msa) MsaPipeline();
+    ctx->mini.reset();
+}
+
+// one piece: upload, plan, emit, download
+void msa_transform_whole(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, const MsaLayout& lay, uint32_t context_len,
+                         edsx_buf* eds, edsx_buf* seds)
+{
+    hipStream_t st = nullptr;
+    // A plain uniform alignment of some size goes to HBM as a row image whose rows all begin on multiples of 128
+    // bytes (2D copies: free on the way up): the column scan's loads are then aligned (multi_gpu.hip).  Everything
+    // else - small inputs, files the geometry walk does not accept - is copied as it is, and the transform itself
+    // words what is wrong with it.
+    size_t dev_size = msa_size;
+    if (lay.ok) dev_size = (size_t)upload_row_image(msa, lay, 0, lay.L, ctx->d_in, ctx->host_tmp, st).bytes;
+    else {
+        ctx->d_in.ensure(msa_size);
+        EDSX_HIP(hipMemcpyAsync(ctx->d_in.ptr, msa, msa_size, hipMemcpyHostToDevice, st));
+    }
+    uint64_t E = 0, Q = 0;
+    ctx->msa.plan(ctx->d_in.as<uint8_t>(), dev_size, context_len, st, &E, &Q);
+    ctx->d_eds.ensure(E + 16);
+    ctx->d_seds.ensure(Q + 16);
+    ctx->msa.emit(ctx->d_eds.as<uint8_t>(), ctx->d_seds.as<uint8_t>(), st);
+    take(eds, E);
+    take(seds, Q);
+    PinnedDownload::copy(eds->data, ctx->d_eds.ptr, E, st);
+    PinnedDownload::copy(seds->data, ctx->d_seds.ptr, Q, st);
+}
+
+// K column batches; false: this input is not cut (see msa_transform_batched)
+bool msa_transform_in_batches(edsx_ctx* ctx, const uint8_t* msa, const MsaLayout& lay, uint32_t context_len, int K,
+                              edsx_buf* eds, edsx_buf* seds)
+{
+    if (!ctx->mini) ctx->mini.reset(new MsaPipeline());
+    const BatchResources R{&ctx->msa, ctx->mini.get(), &ctx->d_in, &ctx->d_eds, &ctx->d_seds, &ctx->d_mini, &ctx->host_tmp};
+    HostBytes e, q;
+    if (!msa_transform_batched(R, msa, lay, context_len, K, e, q, nullptr)) return false;
+    eds->size = e.size; eds->data = e.release();
+    seds->size = q.size; seds->data = q.release();
+    return true;
 }
 
 } // namespace
@@ -111,6 +162,8 @@ int edsx_msa_emit_device(edsx_ctx* ctx, uint8_t* d_eds, uint8_t* d_seds, void* s
         ctx->msa.emit(d_eds, d_seds, static_cast<hipStream_t>(stream));
     });
 }
+
+int edsx_msa_last_batches(const edsx_ctx* ctx) { return ctx ? ctx->last_batches : 0; }
 
 int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info)
 {
@@ -215,28 +268,48 @@ int edsx_msa_transform(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint3
     return guarded(ctx, [&] {
         if (!msa || !eds || !seds) throw ParamError("null argument");
         if (msa_size == 0) throw FormatError("Invalid MSA: empty input");
-        hipStream_t st = nullptr;
-        // A plain uniform alignment of some size goes to HBM as a row image whose rows all begin on multiples of 128
-        // bytes (2D copies: free on the way up): the column scan's loads are then aligned (multi_gpu.hip).  Everything
-        // else - small inputs, files the geometry walk does not accept - is copied as it is, and the transform itself
-        // words what is wrong with it.
         MsaLayout lay;
         if (msa_size >= ((size_t)1 << 20)) lay = msa_layout(msa, msa_size);
-        size_t dev_size = msa_size;
-        if (lay.ok) dev_size = (size_t)upload_row_image(msa, lay, 0, lay.L, ctx->d_in, ctx->host_tmp, st).bytes;
-        else {
-            ctx->d_in.ensure(msa_size);
-            EDSX_HIP(hipMemcpyAsync(ctx->d_in.ptr, msa, msa_size, hipMemcpyHostToDevice, st));
+        std::string oom;
+        ctx->last_batches = 0;
+        try { msa_transform_whole(ctx, msa, msa_size, lay, context_len, eds, seds); ctx->last_batches = 1; return; }
+        catch (const OutOfDeviceMemory& ex) { oom = ex.what(); }
+        // The alignment and its tables do not fit the device in one piece: column batches, each with the working set of
+        // a K-th of the columns (the reference streams an alignment of any size, msa_transforms.cpp:36-90)
+        edsx_buf_free(eds); edsx_buf_free(seds);
+        for (int K = 2; K <= 256 && lay.ok; K *= 2) {
+            release_msa_buffers(ctx);
+            try {
+                if (!msa_transform_in_batches(ctx, msa, lay, context_len, K, eds, seds)) break;
+                ctx->last_batches = K;
+                return;
+            } catch (const OutOfDeviceMemory& ex) { oom = ex.what(); edsx_buf_free(eds); edsx_buf_free(seds); }
         }
-        uint64_t E = 0, Q = 0;
-        ctx->msa.plan(ctx->d_in.as<uint8_t>(), dev_size, context_len, st, &E, &Q);
-        ctx->d_eds.ensure(E + 16);
-        ctx->d_seds.ensure(Q + 16);
-        ctx->msa.emit(ctx->d_eds.as<uint8_t>(), ctx->d_seds.as<uint8_t>(), st);
-        take(eds, E);
-        take(seds, Q);
-        PinnedDownload::copy(eds->data, ctx->d_eds.ptr, E, st);
-        PinnedDownload::copy(seds->data, ctx->d_seds.ptr, Q, st);
+        release_msa_buffers(ctx);
+        throw LimitError("the alignment does not fit the device, in one piece or in column batches (" + oom + ")");
+    });
+}
+
+int edsx_msa_transform_batched(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint32_t context_len, int batches,
+                               edsx_buf* eds, edsx_buf* seds, int* batches_used)
+{
+    if (eds) { eds->data = nullptr; eds->size = 0; }
+    if (seds) { seds->data = nullptr; seds->size = 0; }
+    if (batches_used) *batches_used = 0;
+    return guarded(ctx, [&] {
+        if (!msa || !eds || !seds) throw ParamError("null argument");
+        if (batches < 1) throw ParamError("edsx_msa_transform_batched: batches must be at least 1");
+        if (msa_size == 0) throw FormatError("Invalid MSA: empty input");
+        const MsaLayout lay = msa_layout(msa, msa_size);
+        ctx->last_batches = 0;
+        if (batches > 1 && lay.ok && msa_transform_in_batches(ctx, msa, lay, context_len, batches, eds, seds)) {
+            if (batches_used) *batches_used = batches;
+            ctx->last_batches = batches;
+            return;
+        }
+        msa_transform_whole(ctx, msa, msa_size, lay, context_len, eds, seds);
+        if (batches_used) *batches_used = 1;
+        ctx->last_batches = 1;
     });
 }
 

@@ -14,6 +14,7 @@
 namespace edsx {
 
 struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct OutOfDeviceMemory : DeviceError { using DeviceError::DeviceError; };     // hipMalloc said so: the caller may retry with less
 
 #define EDSX_HIP(call)                                                                        \
     do {                                                                                      \

@@ -171,6 +171,7 @@ struct FinParams {
     u64* bytes; u64* sbytes;                              // per final string: eds bytes / seds bytes (-> offsets)
     const uint8_t* chars; const u64* str_off;
     uint8_t* out; uint8_t* sout; u64* err; int compact, linear;
+    u32* spill = nullptr; u32 spill_depth = 0;            // serial walk after more than FIN_STACK - 2 rounds: a stack per string in HBM
 };
 
 __global__ void k_fin_list(FinParams p)
@@ -208,13 +209,24 @@ __global__ void k_fin_list(FinParams p)
 // tree's depth, not its number of leaves.  Leaves of 256 bytes and more are copied by the whole workgroup.  A stack that
 // would overflow (far beyond 256 x depth items) sends the batch to the serial walk below, which also has the only
 // depth limit left.
-constexpr u32 FW_STACK = 4096, FW_LONG = 32, FW_LONG_MIN = 256;
+#if defined(EDSX_EXPERIMENTS) && defined(EDSX_FW_STACK)
+constexpr u32 FW_STACK = EDSX_FW_STACK;                   // (test builds: see build.py)
+#else
+constexpr u32 FW_STACK = 4096;
+#endif
+constexpr u32 FW_LONG = 32, FW_LONG_MIN = 256;
 
-// Depth of an entry's merge tree <= number of rounds its symbol took part in.  Every round merges at least half
-// of each run of mergeable pairs (greedy non-overlapping pairs, eds_transforms.cpp:63-66), so a symbol built from
-// 2^32 leaves - more than the pool can hold - is at most ~33 levels deep plus the rounds in which a product
-// collapsed and reopened a run; 96 is far beyond what fits in the 32-bit entry pool.  An overflow still raises.
+// Depth of an entry's merge tree <= number of rounds that were run (an entry made in round k has children from earlier
+// rounds).  Every round merges at least half of each run of mergeable pairs (greedy non-overlapping pairs,
+// eds_transforms.cpp:63-66), so trees are normally ~log2(run length) deep; only products that collapse and reopen a run
+// round after round make deeper ones.  A merge of up to FIN_STACK - 2 rounds walks with the stack in registers /
+// scratch below; after more rounds (the reference allows 10 000, eds_transforms.cpp:335) the host hands every string a
+// stack of rounds + 2 entries in HBM (FinParams::spill), so no depth is refused.
+#if defined(EDSX_EXPERIMENTS) && defined(EDSX_FIN_STACK)
+constexpr int FIN_STACK = EDSX_FIN_STACK;                 // (test builds: a tiny stack sends ordinary inputs through the spill path)
+#else
 constexpr int FIN_STACK = 96;
+#endif
 
 // the serial walk: one thread, one string (fallback of k_fin_write)
 __device__ void fin_eds_direct(const FinParams& p, u64 t)
@@ -227,7 +239,9 @@ __device__ void fin_eds_direct(const FinParams& p, u64 t)
         if (wr) *o = first ? '{' : ',';
         o += wr ? 1 : 0;
     }
-    u32 stack[FIN_STACK];
+    u32 local[FIN_STACK];
+    u32* stack = p.spill ? p.spill + t * (u64)p.spill_depth : local;
+    const int cap = p.spill ? (int)p.spill_depth : FIN_STACK;
     int sp = 0;
     stack[sp++] = p.fin_ent[t];
     while (sp) {
@@ -236,7 +250,7 @@ __device__ void fin_eds_direct(const FinParams& p, u64 t)
             const u64 s0 = p.str_off[p.pool.right[e]], s1 = p.str_off[p.pool.right[e] + 1];
             for (u64 c = s0; c < s1; c++) *o++ = p.chars[c];
         } else {
-            if (sp + 2 > FIN_STACK) { *p.err = 1; break; }
+            if (sp + 2 > cap) { *p.err = 1; break; }
             stack[sp++] = p.pool.right[e];
             stack[sp++] = p.pool.left[e];
         }
@@ -366,64 +380,119 @@ __global__ void k_fin_write_sources(FinParams p, u64 nstr)
 // The .eds / .seds text goes to HBM as it is and is tokenised there (eds.cpp:39-155 / :268-355 rules) straight into
 // the layout above: no host arrays, no per-array upload.  The kernels only accept text every byte of which they can
 // place (no whitespace before the end, braces alternate, no comma outside braces, ids are digits that fit an int,
-// no empty source set); anything else raises `bad`, and the host tokenisers — which own the reference's error texts
-// and its treatment of odd but legal text — take the input instead.
-//   marks    brace bytes publish 2*(i+1)+is_open; an inclusive max-scan gives every byte the last brace at or
-//            before it, i.e. whether it sits inside a group
-//   counts   per byte: characters | string starts << 32 (one sum-scan), symbol starts (a second one)
-struct TokCtl { u64 n, bad, total_cs, total_sym, maxid, total_sets, pad0, pad1; };
+// no empty source set); anything else raises `bad`, and the host tokenisers - which own the reference's error texts
+// and its treatment of odd but legal text - take the input instead.
+// Two passes over 4 KB blocks of the text (256 threads x 16 bytes), nothing kept per byte:
+//   count   per block: '{', '}', ',' (ids for .seds), starts of bare runs, characters - what a byte IS needs only
+//           the byte in front of it
+//   scan    of the block counts (three packed u64 arrays, one multi-array pass)
+//   fill    the same classification again; block prefix + a scan inside the workgroup give every byte its place in
+//           chars / str_off / sym_first (its source set), and the brace depth in front of it - which is where the
+//           text is validated: a byte that does not fit its depth raises `bad` (the arrays are sized by the counts
+//           either way, so a text that is rejected writes inside them)
+struct TokCtl { u64 n, bad, nblk, totA, totB, totC, maxid, pad; };
+constexpr u32 TOK_BLOCK = 4096;
 
 __device__ __forceinline__ bool tok_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+__device__ __forceinline__ bool tok_digit(uint8_t c) { return c >= '0' && c <= '9'; }
 
-__global__ void k_tok_mark(const uint8_t* __restrict__ raw, u64 n, u64* __restrict__ bm, TokCtl* ctl, int seds)
+struct TokSums { u64 a, b, c; };
+// exclusive prefix of `mine` over the 256 threads of the workgroup; `total` = sum over all of them
+__device__ __forceinline__ TokSums tok_block_scan(const TokSums& mine, TokSums* wsum, TokSums& total)
 {
-    bool bad = false;
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const uint8_t c = raw[i];
-        bm[i] = c == '{' ? 2 * (i + 1) + 1 : (c == '}' ? 2 * (i + 1) : 0);
-        if (tok_ws(c)) bad = true;
-        if (seds && !(c == '{' || c == '}' || c == ',' || (c >= '0' && c <= '9'))) bad = true;
+    TokSums inc = mine;
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 ta = __shfl_up(inc.a, o, 64), tb = __shfl_up(inc.b, o, 64), tc = __shfl_up(inc.c, o, 64);
+        if (lane >= (u32)o) { inc.a += ta; inc.b += tb; inc.c += tc; }
     }
-    if (bad) ctl->bad = 1;
+    __syncthreads();                                          // (wsum of the previous block has been read)
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    TokSums ex{inc.a - mine.a, inc.b - mine.b, inc.c - mine.c};
+    total = TokSums{0, 0, 0};
+    for (u32 w = 0; w < 4; w++) {
+        const TokSums t = wsum[w];
+        if (w < wv) { ex.a += t.a; ex.b += t.b; ex.c += t.c; }
+        total.a += t.a; total.b += t.b; total.c += t.c;
+    }
+    return ex;
+}
+// the 16 bytes of this thread (nb of them exist) and the byte in front of them (0: start of the text)
+__device__ __forceinline__ void tok_load(const uint8_t* raw, u64 n, u64 i0, uint8_t (&c)[16], int& nb, uint8_t& prev)
+{
+    nb = i0 < n ? (n - i0 < 16 ? (int)(n - i0) : 16) : 0;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (nb > 0) v = *reinterpret_cast<const uint4*>(raw + i0);       // (the buffer has 16 bytes of slack behind the text)
+    __builtin_memcpy(c, &v, 16);
+    prev = (nb > 0 && i0 > 0) ? raw[i0 - 1] : 0;
 }
 
-// .eds: cs[i] = is_char | string_start << 32, sy[i] = symbol_start
-__global__ void k_tok_eds_flags(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ last, u64* __restrict__ cs,
-                                u64* __restrict__ sy, TokCtl* ctl)
+// .eds.  A = '{' | '}' << 32, B = ',' | bare-run starts << 32, C = characters.  Strings open at '{', ',' and at the
+// first character of a bare run (eds.cpp:848-878: text outside braces is a symbol of one string), symbols at '{' and there.
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_tok_eds(const uint8_t* __restrict__ raw, u64 n, u64* __restrict__ A, u64* __restrict__ B,
+                                                 u64* __restrict__ C, uint8_t* __restrict__ chars, u64* __restrict__ str_off,
+                                                 u64* __restrict__ sym_first, TokCtl* ctl)
 {
+    __shared__ TokSums wsum[4];
+    const u64 nblk = (n + TOK_BLOCK - 1) / TOK_BLOCK;
     bool bad = false;
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const uint8_t c = raw[i];
-        const bool inside = i > 0 && (last[i - 1] & 1);
-        u64 ch = 0, st = 0, sm = 0;
-        if (c == '{') { if (inside) bad = true; st = 1; sm = 1; }
-        else if (c == '}') { if (!inside) bad = true; }
-        else if (c == ',') { if (!inside) bad = true; st = 1; }
-        else {
-            ch = 1;
-            if (!inside && (i == 0 || raw[i - 1] == '}')) { st = 1; sm = 1; }      // a bare run opens a symbol (eds.cpp:848-878)
+    for (u64 blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const u64 i0 = blk * TOK_BLOCK + (u64)threadIdx.x * 16;
+        uint8_t c[16], prev;
+        int nb;
+        tok_load(raw, n, i0, c, nb, prev);
+        TokSums mine{0, 0, 0};
+        uint8_t pv = prev;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < nb) {
+                const uint8_t ch = c[k];
+                if (ch == '{') mine.a += 1;
+                else if (ch == '}') mine.a += 1ull << 32;
+                else if (ch == ',') mine.b += 1;
+                else {
+                    mine.c += 1;
+                    if (i0 + k == 0 || pv == '}') mine.b += 1ull << 32;
+                    if (!FILL && tok_ws(ch)) bad = true;
+                }
+                pv = ch;
+            }
         }
-        if (i == n - 1 && (last[i] & 1)) bad = true;                                 // unterminated group
-        cs[i] = ch | (st << 32);
-        sy[i] = sm;
+        TokSums total;
+        TokSums ex = tok_block_scan(mine, wsum, total);
+        if constexpr (!FILL) {
+            if (threadIdx.x == 0) { A[blk] = total.a; B[blk] = total.b; C[blk] = total.c; }
+        } else {
+            ex.a += A[blk]; ex.b += B[blk]; ex.c += C[blk];
+            u64 o = ex.a & 0xffffffffull, cl = ex.a >> 32, cm = ex.b & 0xffffffffull, br = ex.b >> 32, h = ex.c;
+            pv = prev;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < nb) {
+                    const uint8_t ch = c[k];
+                    const u64 depth = o - cl;                            // braces open in front of this byte
+                    const u64 sidx = o + cm + br;
+                    if (ch == '{') { if (depth != 0) bad = true; str_off[sidx] = h; sym_first[o + br] = sidx; o++; }
+                    else if (ch == '}') { if (depth != 1) bad = true; cl++; }
+                    else if (ch == ',') { if (depth != 1) bad = true; str_off[sidx] = h; cm++; }
+                    else {
+                        if (depth > 1) bad = true;
+                        if (i0 + k == 0 || pv == '}') { str_off[sidx] = h; sym_first[o + br] = sidx; br++; }
+                        chars[h] = ch; h++;
+                    }
+                    pv = ch;
+                }
+            }
+        }
     }
     if (bad) ctl->bad = 1;
-}
-
-__global__ void k_tok_eds_fill(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ cs, const u64* __restrict__ css,
-                               const u64* __restrict__ sy, const u64* __restrict__ sys, uint8_t* __restrict__ chars,
-                               u64* __restrict__ str_off, u64* __restrict__ sym_first, const TokCtl* ctl)
-{
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const u64 f = cs[i], sc = css[i];
-        const u64 cpos = sc & 0xffffffffull, sidx = sc >> 32;
-        if (f & 1) chars[cpos] = raw[i];
-        if (f >> 32) str_off[sidx] = cpos;
-        if (sy[i]) sym_first[sys[i]] = sidx;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        str_off[ctl->total_cs >> 32] = ctl->total_cs & 0xffffffffull;
-        sym_first[ctl->total_sym] = ctl->total_cs >> 32;
+    if (FILL && blockIdx.x == 0 && threadIdx.x == 0) {
+        const u64 o = ctl->totA & 0xffffffffull, cl = ctl->totA >> 32, cm = ctl->totB & 0xffffffffull, br = ctl->totB >> 32;
+        if (o != cl) ctl->bad = 1;                                       // unterminated group
+        str_off[o + cm + br] = ctl->totC;
+        sym_first[o + br] = o + cm + br;
     }
 }
 
@@ -455,50 +524,73 @@ __device__ __forceinline__ bool tok_number(const uint8_t* raw, u64 i, u64 n, u64
     return true;
 }
 
-// cs[i] = set_start | id_start << 32
-__global__ void k_tok_seds_flags(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ last, u64* __restrict__ cs,
-                                 TokCtl* ctl)
+// .seds.  A = '{' | '}' << 32, B = ids (an id starts at a digit that does not follow a digit).  COUNT also finds the
+// largest id (the width of the path bitsets); FILL validates and sets bit `id` of the byte's source set.
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_tok_seds(const uint8_t* __restrict__ raw, u64 n, u64* __restrict__ A, u64* __restrict__ B,
+                                                  u64* __restrict__ C, u64* __restrict__ bits, u32 W, TokCtl* ctl)
 {
+    __shared__ TokSums wsum[4];
+    const u64 nblk = (n + TOK_BLOCK - 1) / TOK_BLOCK;
     bool bad = false;
     u64 mx = 0;
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const uint8_t c = raw[i];
-        const bool inside = i > 0 && (last[i - 1] & 1);
-        u64 ss = 0, ns = 0;
-        if (c == '{') { if (inside) bad = true; ss = 1; }
-        else if (c == '}') { if (!inside) bad = true; }
-        else {
-            if (!inside) bad = true;
-            if (c != ',' && (i == 0 || !(raw[i - 1] >= '0' && raw[i - 1] <= '9'))) {
-                u64 v;
-                if (!tok_number(raw, i, n, v)) bad = true;
-                mx = v > mx ? v : mx;
-                ns = 1;
+    for (u64 blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const u64 i0 = blk * TOK_BLOCK + (u64)threadIdx.x * 16;
+        uint8_t c[16], prev;
+        int nb;
+        tok_load(raw, n, i0, c, nb, prev);
+        TokSums mine{0, 0, 0};
+        uint8_t pv = prev;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < nb) {
+                const uint8_t ch = c[k];
+                if (ch == '{') mine.a += 1;
+                else if (ch == '}') mine.a += 1ull << 32;
+                else if (tok_digit(ch)) {
+                    if (!tok_digit(pv)) {
+                        mine.b += 1;
+                        if (!FILL) { u64 v; if (!tok_number(raw, i0 + k, n, v)) bad = true; mx = v > mx ? v : mx; }
+                    }
+                } else if (ch != ',') bad = true;
+                pv = ch;
             }
         }
-        if (i == n - 1 && (last[i] & 1)) bad = true;
-        cs[i] = ss | (ns << 32);
-    }
-    if (bad) ctl->bad = 1;
-    if (mx) atomicMax((unsigned long long*)&ctl->maxid, (unsigned long long)mx);
-}
-
-__global__ void k_tok_seds_fill(const uint8_t* __restrict__ raw, u64 n, const u64* __restrict__ last, const u64* __restrict__ cs,
-                                const u64* __restrict__ css, u64* __restrict__ bits, u32 W, TokCtl* ctl)
-{
-    bool bad = false;
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        if (cs[i] >> 32) {
-            u64 v;
-            tok_number(raw, i, n, v);
-            const u64 set = (css[i] & 0xffffffffull) - 1;                            // sets opened before this byte
-            atomicOr((unsigned long long*)&bits[set * W + (v >> 6)], 1ull << (v & 63));
-        } else if (raw[i] == '}') {
-            const u64 open = (last[i - 1] >> 1) - 1;                                 // its '{' (validated by the flags pass)
-            if ((css[i] >> 32) == (css[open] >> 32)) bad = true;                     // empty path set
+        TokSums total;
+        TokSums ex = tok_block_scan(mine, wsum, total);
+        if constexpr (!FILL) {
+            if (threadIdx.x == 0) { A[blk] = total.a; B[blk] = total.b; C[blk] = 0; }
+        } else {
+            ex.a += A[blk];
+            u64 o = ex.a & 0xffffffffull, cl = ex.a >> 32;
+            pv = prev;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < nb) {
+                    const uint8_t ch = c[k];
+                    const u64 depth = o - cl;
+                    if (ch == '{') { if (depth != 0) bad = true; o++; }
+                    else {
+                        if (depth != 1) bad = true;
+                        if (ch == '}') {
+                            u64 q = i0 + k;                              // a set of commas only is empty (eds.cpp:330)
+                            while (q > 0 && raw[q - 1] == ',') q--;
+                            if (q == 0 || raw[q - 1] == '{') bad = true;
+                            cl++;
+                        } else if (tok_digit(ch) && !tok_digit(pv) && depth == 1) {
+                            u64 v;
+                            tok_number(raw, i0 + k, n, v);
+                            atomicOr((unsigned long long*)&bits[(o - 1) * W + (v >> 6)], 1ull << (v & 63));
+                        }
+                    }
+                    pv = ch;
+                }
+            }
         }
     }
     if (bad) ctl->bad = 1;
+    if (!FILL && mx) atomicMax((unsigned long long*)&ctl->maxid, (unsigned long long)mx);
+    if (FILL && blockIdx.x == 0 && threadIdx.x == 0 && (ctl->totA & 0xffffffffull) != (ctl->totA >> 32)) ctl->bad = 1;
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -676,33 +768,37 @@ bool MergePipeline::tokenize_device(const uint8_t* eds, size_t eds_n, const uint
     while (send && std::isspace(seds[send - 1])) send--;
     if (end == 0 || end >= 0xfffffff0ull || (linear && (send == 0 || send >= 0xfffffff0ull))) return false;
     const size_t nmax = std::max(end, send);
-    if (!device_scratch_fits(41 * nmax)) return false;          // raw text + five u64 arrays per byte
+    if (!device_scratch_fits(nmax + nmax / 64)) return false;   // the raw text + three counters per 4 KB block
+    const u64 nblk_max = (nmax + TOK_BLOCK - 1) / TOK_BLOCK;
     d_raw_.ensure(nmax + 16);
-    for (DevBuf* b : {&tk_a_, &tk_b_, &tk_c_, &tk_d_, &tk_e_}) b->ensure(8 * (nmax + 2));
-    scan_tmp_.ensure(8 * ((nmax + 2) / SCAN_TILE + 4));
+    for (DevBuf* b : {&tk_a_, &tk_b_, &tk_c_}) b->ensure(8 * (nblk_max + 2));
+    scan_tmp_.ensure(8 * 3 * (nblk_max / SCAN_TILE + 4));
     TokCtl* ctl = ctl_.as<TokCtl>();
     TokCtl h{};
-    h.n = end;
+    h.n = end; h.nblk = (end + TOK_BLOCK - 1) / TOK_BLOCK;
     EDSX_HIP(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, st));
     EDSX_HIP(hipMemcpyAsync(d_raw_.ptr, eds, end, hipMemcpyHostToDevice, st));
     const uint8_t* raw = d_raw_.as<uint8_t>();
-    u64 *a = tk_a_.as<u64>(), *b = tk_b_.as<u64>(), *c = tk_c_.as<u64>(), *d = tk_d_.as<u64>(), *e = tk_e_.as<u64>();
-    hipLaunchKernelGGL(k_tok_mark, dim3(2048), dim3(256), 0, st, raw, (u64)end, a, ctl, 0);
-    inclusive_max_scan_u64(a, a, &ctl->n, &ctl->pad0, scan_tmp_.as<u64>(), st);
-    hipLaunchKernelGGL(k_tok_eds_flags, dim3(2048), dim3(256), 0, st, raw, (u64)end, a, b, c, ctl);
-    exclusive_scan_u64(b, d, &ctl->n, &ctl->total_cs, scan_tmp_.as<u64>(), st);
-    exclusive_scan_u64(c, e, &ctl->n, &ctl->total_sym, scan_tmp_.as<u64>(), st);
+    u64 *a = tk_a_.as<u64>(), *b = tk_b_.as<u64>(), *c = tk_c_.as<u64>();
+    const unsigned grid = (unsigned)std::min<u64>(h.nblk, 8192);
+    hipLaunchKernelGGL(k_tok_eds<false>, dim3(grid), dim3(256), 0, st, raw, (u64)end, a, b, c, (uint8_t*)nullptr, (u64*)nullptr,
+                       (u64*)nullptr, ctl);
+    {
+        ScanSet<3> ss{{a, b, c}, {a, b, c}, {&ctl->totA, &ctl->totB, &ctl->totC}};
+        exclusive_scan_multi<3>(ss, &ctl->nblk, scan_tmp_.as<u64>(), st);
+    }
     EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipStreamSynchronize(st));
     if (h.bad) return false;
-    const u64 nchars = h.total_cs & 0xffffffffull;
-    m = h.total_cs >> 32;
-    n0 = h.total_sym;
+    const u64 opens = h.totA & 0xffffffffull, commas = h.totB & 0xffffffffull, bare = h.totB >> 32;
+    const u64 nchars = h.totC;
+    m = opens + commas + bare;
+    n0 = opens + bare;
     if (n0 == 0 || m == 0 || m >= 0xfffffff0ull) return false;
     d_chars_.ensure(nchars + 16);
     d_str_off_.ensure(8 * (m + 1));
     d_sym_first_.ensure(8 * (n0 + 1));
-    hipLaunchKernelGGL(k_tok_eds_fill, dim3(2048), dim3(256), 0, st, raw, (u64)end, b, d, c, e, d_chars_.as<uint8_t>(),
+    hipLaunchKernelGGL(k_tok_eds<true>, dim3(grid), dim3(256), 0, st, raw, (u64)end, a, b, c, d_chars_.as<uint8_t>(),
                        d_str_off_.as<u64>(), d_sym_first_.as<u64>(), ctl);
     const size_t pool_cap = std::max<size_t>(2 * m + 1024, 4096);
     left_.ensure(4 * pool_cap); right_.ensure(4 * pool_cap); elen_.ensure(4 * pool_cap);
@@ -715,28 +811,32 @@ bool MergePipeline::tokenize_device(const uint8_t* eds, size_t eds_n, const uint
     EDSX_HIP(hipMemcpyAsync(sf_head, d_sym_first_.as<u64>(), 16, hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipMemcpyAsync(sf_tail, d_sym_first_.as<u64>() + (n0 - 1), 16, hipMemcpyDeviceToHost, st));
     EDSX_HIP(hipMemcpyAsync(so_head, d_str_off_.as<u64>(), 16, hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));     // `bad` of the fill pass (brace depth)
+    EDSX_HIP(hipStreamSynchronize(st));
+    if (h.bad) return false;
     if (linear) {
         h = TokCtl{};
-        h.n = send;
-        EDSX_HIP(hipStreamSynchronize(st));                      // the small read-backs above land before h is reused
+        h.n = send; h.nblk = (send + TOK_BLOCK - 1) / TOK_BLOCK;
         EDSX_HIP(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, st));
         EDSX_HIP(hipMemcpyAsync(d_raw_.ptr, seds, send, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_tok_mark, dim3(2048), dim3(256), 0, st, raw, (u64)send, a, ctl, 1);
-        inclusive_max_scan_u64(a, a, &ctl->n, &ctl->pad0, scan_tmp_.as<u64>(), st);
-        hipLaunchKernelGGL(k_tok_seds_flags, dim3(2048), dim3(256), 0, st, raw, (u64)send, a, b, ctl);
-        exclusive_scan_u64(b, d, &ctl->n, &ctl->total_sets, scan_tmp_.as<u64>(), st);
+        const unsigned sgrid = (unsigned)std::min<u64>(h.nblk, 8192);
+        hipLaunchKernelGGL(k_tok_seds<false>, dim3(sgrid), dim3(256), 0, st, raw, (u64)send, a, b, c, (u64*)nullptr, 0u, ctl);
+        {
+            ScanSet<3> ss{{a, b, c}, {a, b, c}, {&ctl->totA, &ctl->totB, &ctl->totC}};
+            exclusive_scan_multi<3>(ss, &ctl->nblk, scan_tmp_.as<u64>(), st);
+        }
         EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
         EDSX_HIP(hipStreamSynchronize(st));
-        if (h.bad || (h.total_sets & 0xffffffffull) != m) return false;   // the host path words the error
+        if (h.bad || (h.totA & 0xffffffffull) != m) return false;   // the host path words the error
         W = (u32)(h.maxid / 64 + 1);
         bits_.ensure(8 * pool_cap * W);
         EDSX_HIP(hipMemsetAsync(bits_.ptr, 0, 8 * (size_t)m * W, st));
-        hipLaunchKernelGGL(k_tok_seds_fill, dim3(2048), dim3(256), 0, st, raw, (u64)send, a, b, d, bits_.as<u64>(), W, ctl);
+        hipLaunchKernelGGL(k_tok_seds<true>, dim3(sgrid), dim3(256), 0, st, raw, (u64)send, a, b, c, bits_.as<u64>(), W, ctl);
         EDSX_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+        if (h.bad) return false;
     }
-    EDSX_HIP(hipStreamSynchronize(st));
     EDSX_HIP(hipGetLastError());
-    if (linear && h.bad) return false;
     head_single = sf_head[1] - sf_head[0] == 1;
     tail_single = sf_tail[1] - sf_tail[0] == 1;
     head_len = so_head[1] - so_head[0];
@@ -1068,6 +1168,7 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
         iteration++;
     }
     if (iteration >= MAX_ITERATIONS) throw FormatError("Maximum iterations reached without convergence");
+    rounds_run_ = iteration;
     mark("merge rounds");
 
     // ---- symbol range of a partitioned merge: did the sentinels stay out of every merge?  Merged symbols get
@@ -1109,6 +1210,10 @@ void MergePipeline::run(const uint8_t* eds, size_t eds_n, const uint8_t* seds, s
     d_out_.ensure(E + 16);
     if (linear) d_sout_.ensure(Q + 16);
     fp.out = d_out_.as<uint8_t>(); fp.sout = d_sout_.as<uint8_t>();
+    if (rounds_run_ + 2 > (u64)FIN_STACK && nstr) {          // trees may be deeper than the serial walk's own stack
+        fin_spill_.ensure(4 * nstr * (rounds_run_ + 2));
+        fp.spill = fin_spill_.as<u32>(); fp.spill_depth = (u32)(rounds_run_ + 2);
+    }
     {
         // strings per workgroup: about 16 KB of text (a power of two, at most one string per thread)
         const u64 mean = nstr ? std::max<u64>(1, E / nstr) : 1;

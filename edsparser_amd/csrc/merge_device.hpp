@@ -45,7 +45,8 @@ private:
     bool tokenised_on_device_ = false;
     bool tokenize_device(const uint8_t* eds, size_t eds_n, const uint8_t* seds, size_t seds_n, bool linear, hipStream_t st,
                          u64& n0, u64& m, u32& W, bool& head_single, bool& tail_single, u64& head_len);
-    DevBuf d_raw_, tk_a_, tk_b_, tk_c_, tk_d_, tk_e_, d_sym_first_;
+    DevBuf d_raw_, tk_a_, tk_b_, tk_c_, d_sym_first_, fin_spill_;
+    u64 rounds_run_ = 0;                     // merge rounds of the current call (bounds the depth of the entry trees)
     DevBuf d_chars_, d_str_off_, left_, right_, elen_, bits_, size_[2], ent_off_[2], len1_[2], a_, b_, c_, d_, e_,
            scan_tmp_, ctl_, fin_ent_, fin_flag_, fbytes_, fsbytes_, d_out_, d_sout_;
 };

@@ -1920,7 +1920,7 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
         const u64 a = p.seg_start[seg], b = p.seg_start[seg + 1];
         if (vi == 0 && p0) common(0, p.seg_start[0], a);
         if (seg + 1 < nseg) common(seg + 1, b, p.seg_start[seg + 2]);
-        u64 work_cm = 0, work_wide = 0;
+        u64 work_cm = 0, work_wide = 0, work_wide16 = 0;
         bool done = false;
         if (p.Fraw && ((p.Fraw[a >> 6] >> (a & 63)) & 1ull)) {           // a run the column scan grouped itself?
             const u64 slot = mv.slot(a);
@@ -1929,7 +1929,8 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
                 p.eds_len[seg] = (info >> 8) & 0xffu;
                 p.seds_len[seg] = (u64)(info & 0xffu) + p.tok_total;
                 p.segmeta[seg] = META_REC | META_INLINE | ((info >> 30) & 1u ? META_KIND4 : 0) | slot;
-                work_wide = (info >> 30) & 1u;
+                work_wide = ((info >> 30) & 1u) && (info & 0xffu) <= 8u;            // 5..8 strings / 9..16: the two wide lists
+                work_wide16 = ((info >> 30) & 1u) && (info & 0xffu) > 8u;
                 done = true;
             }
         }
@@ -1953,7 +1954,7 @@ __global__ void __launch_bounds__(256) k_seg_meta(FastParams p)
         // light list: up to ten pure variant columns; heavy list: 11..64 columns or common columns inside
         const bool heavy = work_cm && ((work_cm & CNT_MIXED) || ((work_cm >> 48) & 0xffu) > 10u);
         p.cnt_meta[vi] = work_cm; p.cnt_flag[vi] = work_cm && !heavy ? 1 : 0; p.heavy_flag[vi] = heavy ? 1 : 0;
-        p.wide_flag[vi] = work_wide;
+        p.wide_flag[vi] = work_wide; p.wide16_flag[vi] = work_wide16;
     }
 }
 
@@ -1974,6 +1975,9 @@ __global__ void __launch_bounds__(256) k_work_scatter(FastParams p, const u64* _
         const u64 wpos = p.wide_flag[vi];               // (exclusive scan in place: position; a set flag = the next one is larger)
         const u64 wnext = vi + 1 < nvs ? p.wide_flag[vi + 1] : *p.wide_count;
         if (wnext != wpos) p.wide_list[wpos] = vi;
+        const u64 xpos = p.wide16_flag[vi];
+        const u64 xnext = vi + 1 < nvs ? p.wide16_flag[vi + 1] : *p.wide16_count;
+        if (xnext != xpos) p.wide16_list[xpos] = vi;
     }
 }
 
@@ -2297,7 +2301,8 @@ __global__ void __launch_bounds__(256, HEAVY ? 3 : 4) k_seg_group(FastParams p, 
                 p.eds_len[seg] = 2 + (u64)(G.k - 1) + G.sumlen;
                 p.seds_len[seg] = (u64)G.k + p.tok_total;
                 p.segmeta[seg] = META_REC | (G.k > 16u ? META_KIND8 : G.k > 4u ? META_KIND4 : 0) | vi;
-                if (G.k > 4u) p.wide_list[atomicAdd(p.wide_count, 1ull)] = vi;
+                if (G.k > 8u) p.wide16_list[atomicAdd(p.wide16_count, 1ull)] = vi;
+                else if (G.k > 4u) p.wide_list[atomicAdd(p.wide_count, 1ull)] = vi;
             }
         } else if (lane == 0 && !(!HEAVY && ok == 2)) {
             p.slow_list2[atomicAdd(p.slow_count2, 1ull)] = seg;       // the generic kernels take it
@@ -2800,13 +2805,10 @@ __global__ void __launch_bounds__(256, 5) k_emit_fast2(FastParams p)
 }
 
 // WIDE false: the segments of up to four strings (2-bit group ids); true: those of 5..64 strings
-// KMAX (WIDE): 8 - the segments of 5..8 strings, at four waves per SIMD; 16 - those of 9..64 strings (17..64 sixteen at a
-// time).  Both walk the one work list and skip what is the other's.
-#if defined(EDSX_EXPERIMENTS) && defined(EDSX_WIDE_SINGLE)
-constexpr bool WIDE_SINGLE = true;                      // one wide launch takes every segment of 5..64 strings
-#else
-constexpr bool WIDE_SINGLE = false;
-#endif
+// KMAX (WIDE): 8 - the segments of 5..8 strings, at four waves per SIMD (128 VGPRs); 16 - those of 9..64 strings (17..64
+// sixteen at a time) at two.  A work list each (p.wide_list / p.wide16_list).  (Round 3, each kernel alone on the
+// machine: one launch for all of them 1.28 ms; the two instantiations walking ONE list and skipping what is the
+// other's 0.55 + 0.90 ms.)
 template <bool HAS5, bool WIDE, int KMAX = 16>
 __global__ void __launch_bounds__(256, WIDE ? (KMAX == 8 ? 4 : 2) : 5) k_emit_fast(FastParams p)
 {
@@ -2876,9 +2878,10 @@ __global__ void __launch_bounds__(256, WIDE ? (KMAX == 8 ? 4 : 2) : 5) k_emit_fa
     // descriptor of the one after it) is therefore requested first, the id text of this segment is built in LDS
     // (no global traffic), and only then the wave waits for the prefetch and issues this segment's stores.
     // the wide emitter walks its work list (few segments: no software pipeline)
-    const u64 nwide = *p.wide_count;
+    const u64* const wlist = KMAX == 8 ? p.wide_list : p.wide16_list;
+    const u64 nwide = KMAX == 8 ? *p.wide_count : *p.wide16_count;
     for (u64 it = (u64)blockIdx.x * (blockDim.x >> 6) + wv; it < nwide; it += nw) {
-        const u64 vi = uniform64(p.wide_list[it]);
+        const u64 vi = uniform64(wlist[it]);
         const u64 seg = 2 * vi + p0;
         const u64 meta = uniform64(p.segmeta[seg]);
         const u64 qoff = uniform64(p.seds_len[seg]), eoff = uniform64(p.eds_len[seg]);
@@ -2888,7 +2891,7 @@ __global__ void __launch_bounds__(256, WIDE ? (KMAX == 8 ? 4 : 2) : 5) k_emit_fa
         const u32 hdr0 = uniform32(rc.hv);
         const u32 k = hdr0 & 0xffu, textlen = (hdr0 >> 8) & 0xffu, ncol = (hdr0 >> 16) & 0xffu;
         const bool fast = (meta & META_REC) != 0 && ((meta & (META_KIND4 | META_KIND8)) != 0) == WIDE &&
-                          (!WIDE || WIDE_SINGLE || (KMAX == 8) == (k <= 8u));
+                          (!WIDE || (KMAX == 8) == (k <= 8u));
         uint8_t* gseds = p.seds + qoff;
         // the wait for the prefetched record: called right before this segment's id lists are stored (everything
         // before that point that reads global memory is older than the prefetch or was waited for already)
@@ -3144,7 +3147,7 @@ void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t s
     if (getenv("EDSX_COUNTS"))
         fprintf(stderr, "[edsx] segments %llu variant %llu | grouping list %llu heavy %llu | wide emit %llu | generic %llu + %llu | fused %d\n",
                 (unsigned long long)(l == 0 ? h_.R : h_.nseg), (unsigned long long)h_.nvs, (unsigned long long)h_.cnt_n,
-                (unsigned long long)h_.heavy_n, (unsigned long long)h_.wide_n, (unsigned long long)h_.slow_n,
+                (unsigned long long)h_.heavy_n, (unsigned long long)(h_.wide_n + h_.wide16_n), (unsigned long long)h_.slow_n,
                 (unsigned long long)h_.slow_n2, (int)fuse_);
     if (l == 0) h_.nseg = h_.R;
     *eds_bytes = h_.E;
@@ -3171,7 +3174,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     cnt_.ensure(8 * (nwords + 1));
     wbase_.ensure(8 * (nwords + 1));
     segbase_.ensure(8 * (nwords + 1));
-    scan_tmp_.ensure(8 * 3 * ((L + 2) / SCAN_TILE + 4));      // up to three arrays per pass (exclusive_scan_multi)
+    scan_tmp_.ensure(8 * 4 * ((L + 2) / SCAN_TILE + 4));      // up to four arrays per pass (exclusive_scan_multi)
     run_start_.ensure(8 * (L + 2));
     if (l) { flag_.ensure(8 * (L + 2)); seg_start_.ensure(8 * (L + 2)); }
     eds_len_.ensure(8 * (L + 2));
@@ -3313,8 +3316,8 @@ void MsaPipeline::plan_body(hipStream_t st)
         segmeta_.ensure(8 * (L + 2));
         // list 1: too wide or mixed segments (k_seg_meta), list 2: those the grouping kernel gives up on; together
         // at most all variant segments (<= L/2 + 1)
-        slow_list_.ensure(8 * 3 * (L / 2 + 4));            // + the wide emitter's list
-        cnt_list_.ensure(8 * 10 * (L / 2 + 4));               // work lists of the grouping kernels (ordinal + column descriptor, three times), descriptor and flags per variant segment
+        slow_list_.ensure(8 * 4 * (L / 2 + 4));            // + the wide emitters' two lists
+        cnt_list_.ensure(8 * 11 * (L / 2 + 4));               // work lists of the grouping kernels (ordinal + column descriptor, three times), descriptor and flags per variant segment
         fp_.mv = mv_; fp_.seg_start = seg_start; fp_.nseg_ptr = d_nseg; fp_.segmeta = segmeta_.as<u64>();
         fp_.eds_len = eds_len_.as<u64>(); fp_.seds_len = seds_len_.as<u64>();
         fp_.slow_list = slow_list_.as<u64>(); fp_.slow_count = &dh->slow_n;
@@ -3324,7 +3327,9 @@ void MsaPipeline::plan_body(hipStream_t st)
         fp_.cnt_meta = fp_.heavy_cm + (L / 2 + 4); fp_.cnt_flag = fp_.cnt_meta + (L / 2 + 4); fp_.wide_flag = fp_.cnt_flag + (L / 2 + 4);
         fp_.heavy_flag = fp_.wide_flag + (L / 2 + 4); fp_.heavy2_vi = fp_.heavy_flag + (L / 2 + 4); fp_.heavy2_cm = fp_.heavy2_vi + (L / 2 + 4);
         fp_.heavy2_n = &dh->heavy2_n;
+        fp_.wide16_flag = fp_.heavy2_cm + (L / 2 + 4);
         fp_.wide_list = slow_list_.as<u64>() + 2 * (L / 2 + 4); fp_.wide_count = &dh->wide_n;
+        fp_.wide16_list = slow_list_.as<u64>() + 3 * (L / 2 + 4); fp_.wide16_count = &dh->wide16_n;
         fp_.eds = nullptr; fp_.seds = nullptr; fp_.tok_total = tok_total;
         // one record per variant segment; there are at most as many as variant columns
         fp_.rec_stride = rec_stride((u32)S); fp_.rec_gid = rec_gid_bytes((u32)S);
@@ -3335,12 +3340,12 @@ void MsaPipeline::plan_body(hipStream_t st)
         fp_.long_list = sp.long_list; fp_.long_count = sp.long_count;
         EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, 2 * sizeof(u64), st));
         EDSX_HIP(hipMemsetAsync(&dh->wide_n, 0, 3 * sizeof(u64), st));     // (wide_n is then set by scan_wide, and added to by k_seg_group)
-        EDSX_HIP(hipMemsetAsync(&dh->heavy2_n, 0, sizeof(u64), st));
+        EDSX_HIP(hipMemsetAsync(&dh->heavy2_n, 0, 2 * sizeof(u64), st));    // + wide16_n
         TIMED("k_seg_meta", st, hipLaunchKernelGGL(k_seg_meta, dim3(4096), dim3(256), 0, st, fp_));
         {   // list positions of the light / heavy grouping lists and of the wide emitter's list: one pass
-            ScanSet<3> ss{{fp_.cnt_flag, fp_.heavy_flag, fp_.wide_flag}, {fp_.cnt_flag, fp_.heavy_flag, fp_.wide_flag},
-                          {&dh->cnt_n, &dh->heavy_n, &dh->wide_n}};
-            TIMED("scan_lists", st, exclusive_scan_multi<3>(ss, &dh->nvs, scan_tmp_.as<u64>(), st));
+            ScanSet<4> ss{{fp_.cnt_flag, fp_.heavy_flag, fp_.wide_flag, fp_.wide16_flag}, {fp_.cnt_flag, fp_.heavy_flag, fp_.wide_flag, fp_.wide16_flag},
+                          {&dh->cnt_n, &dh->heavy_n, &dh->wide_n, &dh->wide16_n}};
+            TIMED("scan_lists", st, exclusive_scan_multi<4>(ss, &dh->nvs, scan_tmp_.as<u64>(), st));
         }
         TIMED("k_work_scatter", st, hipLaunchKernelGGL(k_work_scatter, dim3(2048), dim3(256), 0, st, fp_, fp_.cnt_flag, fp_.heavy_flag, &dh->nvs));
         // (The light and the heavy grouping kernel and the generic count are independent, but side by side on three
@@ -3436,6 +3441,53 @@ MsaPipeline::Edges MsaPipeline::edge_info(hipStream_t st)
     return e;
 }
 
+// l-EDS stitch: the first and the last standalone common run of at least min_cols columns (msa_transforms.cpp:153) - the
+// text between two such anchors does not depend on anything outside them
+__global__ void k_anchor_find(const u64* __restrict__ seg_start, const u64* __restrict__ V, u64 nseg, u64 min_cols, u64* __restrict__ out)
+{
+    for (u64 seg = blockIdx.x * (u64)blockDim.x + threadIdx.x; seg < nseg; seg += (u64)gridDim.x * blockDim.x) {
+        const u64 a = seg_start[seg], b = seg_start[seg + 1];
+        const bool variant = (V[a >> 6] >> (a & 63)) & 1ull;
+        if (!variant && b - a >= min_cols) {
+            atomicMin((unsigned long long*)&out[0], (unsigned long long)seg);
+            atomicMax((unsigned long long*)&out[1], (unsigned long long)(seg + 1));
+        }
+    }
+}
+__global__ void k_anchor_read(const u64* __restrict__ seg_start, const u64* __restrict__ eds_off, const u64* __restrict__ seds_off,
+                              u64 nseg, u64 E, u64 Q, u64* __restrict__ out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const u64 first = out[0], last1 = out[1];
+    if (last1 == 0) return;                                   // none
+    const u64 last = last1 - 1;
+    out[2] = seg_start[last]; out[3] = eds_off[last]; out[4] = seds_off[last];
+    out[5] = seg_start[first + 1];
+    out[6] = first + 1 < nseg ? eds_off[first + 1] : E;
+    out[7] = first + 1 < nseg ? seds_off[first + 1] : Q;
+}
+
+MsaPipeline::Anchors MsaPipeline::anchor_info(u64 min_cols, hipStream_t st)
+{
+    if (!planned_) throw ParamError("anchor_info needs a planned alignment");
+    Anchors a{};
+    a.nseg = h_.nseg;
+    idx_tmp_.ensure(16 * sizeof(u64));
+    u64 h[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+    EDSX_HIP(hipMemcpyAsync(idx_tmp_.ptr, h, sizeof(h), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_anchor_find, dim3(1024), dim3(256), 0, st, seg_start_p_, mv_.V, h_.nseg, min_cols, idx_tmp_.as<u64>());
+    hipLaunchKernelGGL(k_anchor_read, dim3(1), dim3(64), 0, st, seg_start_p_, eds_len_.as<u64>(), seds_len_.as<u64>(), h_.nseg,
+                       h_.E, h_.Q, idx_tmp_.as<u64>());
+    EDSX_HIP(hipMemcpyAsync(h, idx_tmp_.ptr, sizeof(h), hipMemcpyDeviceToHost, st));
+    EDSX_HIP(hipStreamSynchronize(st));
+    if (h[1] == 0) return a;                                  // no such run
+    a.found = 1;
+    a.first_seg = h[0]; a.last_seg = h[1] - 1;
+    a.last_col = h[2]; a.last_eds = h[3]; a.last_seds = h[4];
+    a.first_end = h[5]; a.first_eds_end = h[6]; a.first_seds_end = h[7];
+    return a;
+}
+
 // first segment that starts at or after alignment column `col` (binary search over the device table, one
 // 8-byte copy per probe: a reporting / verification helper, not on the transform path)
 MsaPipeline::SegLoc MsaPipeline::locate(u64 col, hipStream_t st)
@@ -3516,11 +3568,9 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
                                                    dim3(256), 0, st, fp));
             };
             if (h_.S >= 1000) {                                          // ids of five bytes exist
-                if (!WIDE_SINGLE) launch_wide(k_emit_fast<true, true, 8>, "k_emit_fast_wide8");
-                launch_wide(k_emit_fast<true, true, 16>, "k_emit_fast_wide16");
+                launch_wide(k_emit_fast<true, true, 8>, "k_emit_fast_wide8"); launch_wide(k_emit_fast<true, true, 16>, "k_emit_fast_wide16");
             } else {
-                if (!WIDE_SINGLE) launch_wide(k_emit_fast<false, true, 8>, "k_emit_fast_wide8");
-                launch_wide(k_emit_fast<false, true, 16>, "k_emit_fast_wide16");
+                launch_wide(k_emit_fast<false, true, 8>, "k_emit_fast_wide8"); launch_wide(k_emit_fast<false, true, 16>, "k_emit_fast_wide16");
             }
         }
         ep.gcache_stride = gc_stride_; ep.gcache_cap = gc_region_ / gc_stride_;

@@ -29,7 +29,13 @@ struct DevBuf {
         if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
         size_t want = (bytes + 255) & ~(size_t)255;
         hipError_t e = hipMalloc(&ptr, want);
-        if (e != hipSuccess) { ptr = nullptr; throw DeviceError(std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            (void)hipGetLastError();                              // (the failure is reported here, not by the next launch check)
+            const std::string what = std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e);
+            if (e == hipErrorOutOfMemory) throw OutOfDeviceMemory(what);
+            throw DeviceError(what);
+        }
         cap = want;
     }
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
@@ -91,6 +97,7 @@ struct MsaHdr {
     u64 nvs;           // number of variant segments
     u64 long_n;        // common segments the variant emitters leave to k_emit_common_long (very long ones, and a final one)
     u64 heavy2_n;      // segments the light grouping kernel hands to a second heavy pass (other alphabets)
+    u64 wide16_n;      // variant segments of 9..64 strings (wide_n: those of 5..8); adjacent to heavy2_n: cleared together
 };
 
 // One vc column holds the bytes of one variant column in NATURAL row order: byte r = row r, pitch =
@@ -126,8 +133,9 @@ struct FastParams {
     u64* eds_len; u64* seds_len;            // sizes (count pass) == offsets (emit pass, after the scans)
     u64* slow_list; u64* slow_count;        // variant segments left to the generic kernels (k_seg_meta)
     u64* slow_list2; u64* slow_count2;      // ... added by k_seg_group
-    u64* wide_list; u64* wide_count;        // variant segments (ordinals) of 5..64 strings: the wide emitter's work list
-    u64* wide_flag;                         // per variant segment: grouped by the column scan with 5..16 strings (-> wide emitter's list)
+    u64* wide_list; u64* wide_count;        // variant segments (ordinals) of 5..8 strings: work list of the wide emitter's K <= 8 instantiation
+    u64* wide16_list; u64* wide16_count;    // ... of 9..64 strings
+    u64* wide_flag; u64* wide16_flag;       // per variant segment: grouped by the column scan with 5..8 / 9..16 strings (-> those lists)
     u64* cnt_meta; u64* cnt_flag;           // per variant segment: column descriptor (0: not for k_seg_group), flag / list position
     u64* cnt_vi; u64* cnt_cm; u64* cnt_n;   // work list of k_seg_group: ordinal among the variant segments, column descriptor
     u64* heavy_vi; u64* heavy_cm; u64* heavy_n;   // ... of its heavy instantiation (11..64 columns, mixed segments)
@@ -154,6 +162,10 @@ public:
     struct Edges { u64 nseg, fvar, fcols, feds, fseds, lvar, lcols, leds, lseds; };
     Edges edge_info(hipStream_t st);
     void copy_columns(u64 col0, u64 ncols, uint8_t* host_out, hipStream_t st);
+    // first / last common segment of at least min_cols columns: segment numbers, the last one's first column and text
+    // offsets, the first one's end column and the text offsets behind it
+    struct Anchors { u64 nseg, found, first_seg, last_seg, last_col, last_eds, last_seds, first_end, first_eds_end, first_seds_end; };
+    Anchors anchor_info(u64 min_cols, hipStream_t st);
     struct SegLoc { u64 seg, col, eds_off, seds_off; };
     SegLoc locate(u64 col, hipStream_t st);
     bool planned() const { return planned_; }

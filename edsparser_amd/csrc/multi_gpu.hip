@@ -289,12 +289,13 @@ void MultiMsa::transform(const uint8_t* fasta, size_t n, uint32_t context_len, H
     const int N = world();
     if (n == 0) throw FormatError("Invalid MSA: empty input");
     MsaLayout lay;
-    if (context_len == 0 && N > 1) lay = msa_layout(fasta, n);
-    partitioned_ = lay.ok && lay.L >= 2ull * (u64)N;
+    if (N > 1) lay = msa_layout(fasta, n);
+    // (an l-EDS slab needs room for a standalone common run at either end: at least 4 l columns)
+    partitioned_ = lay.ok && lay.L >= 2ull * (u64)N && lay.L / (u64)N >= 4ull * context_len;
     chains_ = 0;
-    if (!partitioned_) {
-        // One GPU: a context length > 0 looks across runs (msa_transforms.cpp:133-190), and a file that is not a plain
-        // uniform alignment gets its error from the transform itself, in the reference's words.
+    auto whole_on_rank0 = [&] {
+        // One GPU: a file that is not a plain uniform alignment gets its error from the transform itself, in the reference's
+        // words; an l-EDS whose slabs have no standalone common run to anchor the stitch on is not partitioned either.
         Rank& r0 = *ranks_[0];
         EDSX_HIP(hipSetDevice(r0.device));
         r0.d_img.ensure(n);
@@ -306,19 +307,22 @@ void MultiMsa::transform(const uint8_t* fasta, size_t n, uint32_t context_len, H
         eds.take(E); seds.take(Q);
         PinnedDownload::copy(eds.data, r0.d_eds.ptr, E, nullptr);
         PinnedDownload::copy(seds.data, r0.d_seds.ptr, Q, nullptr);
-        return;
-    }
+    };
+    if (!partitioned_) { whole_on_rank0(); return; }
     bar_->reset();
+    no_anchor_ = false;
     piece_e_.assign(N, 0); piece_s_.assign(N, 0);
     std::vector<std::thread> th;
-    for (int r = 1; r < N; r++) th.emplace_back([&, r] { run_rank(r, fasta, n, lay, eds, seds); });
-    run_rank(0, fasta, n, lay, eds, seds);
+    auto one = [&](int r) { if (context_len) run_rank_leds(r, fasta, lay, context_len, eds, seds); else run_rank(r, fasta, n, lay, eds, seds); };
+    for (int r = 1; r < N; r++) th.emplace_back([&, r] { one(r); });
+    one(0);
     for (auto& t : th) t.join();
     if (bar_->failed()) {
         const std::string m = bar_->message();
         if (m.rfind("Invalid MSA", 0) == 0) throw FormatError(m);
         throw DeviceError(m);
     }
+    if (no_anchor_) { partitioned_ = false; chains_ = 0; whole_on_rank0(); }
 }
 
 // One rank.  Every phase ends in the thread barrier, which also carries a failure of any rank to all of them: nobody
@@ -453,6 +457,260 @@ void MultiMsa::run_rank(int r, const uint8_t* fasta, size_t n, const MsaLayout& 
         if (!extra_e.empty()) std::memcpy(eds.data + eoff + (ehi - elo), extra_e.data(), extra_e.size());
         if (!extra_s.empty()) std::memcpy(seds.data + soff + (shi - slo), extra_s.data(), extra_s.size());
     });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Context length l > 0 (parse_msa_to_leds_streaming).  An l-EDS joins variant runs with the common runs of fewer than l
+// columns between them; only a common run of at least l columns (or one at either end of the alignment) stands alone
+// (msa_transforms.cpp:133-190).  A slab transformed on its own applies the "at either end" clause at ITS ends, so its
+// text is the alignment's text only between its first and its last standalone run of >= l columns - its anchors: what
+// lies between two anchors depends on nothing outside them.  Every boundary is therefore recomputed from the last
+// anchor of the left slab to the first anchor of the right one (both included: a mini alignment that begins and ends
+// with a standalone run, transformed with the same l), by the left rank; the columns come through one all-gather.
+//   slab r keeps   text[ behind its first anchor .. in front of its last anchor )      (rank 0 from its start, the
+//   last rank to its end), followed by the text of the boundary r | r+1.
+// A slab without two distinct anchors (or one whose anchors lie more than ANCHOR_MAX_COLS from its ends) makes every
+// rank leave; the caller then transforms the whole image on one GPU.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct SlabAnchors {            // twelve u64, exchanged as they are
+    u64 cols, eds_bytes, seds_bytes, ok;
+    u64 tail_col, tail_eds, tail_seds;          // last anchor: its first column, text offsets in front of it
+    u64 head_end, head_eds, head_seds;          // first anchor: the column behind it, text offsets behind it
+    u64 pad0, pad1;
+};
+constexpr u64 ANCHOR_MAX_COLS = 1u << 16;
+}
+
+void MultiMsa::run_rank_leds(int r, const uint8_t* fasta, const MsaLayout& lay, uint32_t l, HostBytes& eds, HostBytes& seds)
+{
+    const int N = world();
+    Rank& me = *ranks_[r];
+    std::string fail;
+    auto phase = [&](auto&& body) -> bool {
+        if (fail.empty() && !bar_->failed()) {
+            try { body(); } catch (const std::exception& ex) { fail = ex.what(); }
+        }
+        bar_->arrive(r, fail.empty() ? nullptr : &fail);
+        return !bar_->failed();
+    };
+    const u64 S = lay.start.size(), L = lay.L;
+    const u64 c0 = L * (u64)r / (u64)N, c1 = L * (u64)(r + 1) / (u64)N, ncols = c1 - c0;
+    hipStream_t st = nullptr;
+    uint64_t E = 0, Q = 0;
+    SlabAnchors mine{};
+    std::vector<SlabAnchors> all(N);
+
+    // ---- 1. slab image -> HBM, plan + emit with the context length, anchors
+    if (!phase([&] {
+            EDSX_HIP(hipSetDevice(me.device));
+            const RowImage ri = upload_row_image(fasta, lay, c0, c1, me.d_img, me.host_img, st);
+            me.slab.plan(me.d_img.as<uint8_t>(), ri.bytes, l, st, &E, &Q);
+            me.d_eds.ensure(E + 16); me.d_seds.ensure(Q + 16);
+            me.slab.emit(me.d_eds.as<uint8_t>(), me.d_seds.as<uint8_t>(), st);
+            const MsaPipeline::Anchors a = me.slab.anchor_info(l, st);
+            mine.cols = ncols; mine.eds_bytes = E; mine.seds_bytes = Q;
+            const bool need_head = r > 0, need_tail = r + 1 < N;
+            bool ok = a.found != 0;
+            if (ok && need_head && need_tail) ok = a.first_seg < a.last_seg;             // two distinct anchors
+            if (ok && need_head) ok = a.first_end <= ANCHOR_MAX_COLS;
+            if (ok && need_tail) ok = ncols - a.last_col <= ANCHOR_MAX_COLS;
+            mine.ok = ok ? 1 : 0;
+            if (ok) {
+                mine.tail_col = need_tail ? a.last_col : ncols; mine.tail_eds = need_tail ? a.last_eds : E; mine.tail_seds = need_tail ? a.last_seds : Q;
+                mine.head_end = need_head ? a.first_end : 0; mine.head_eds = need_head ? a.first_eds_end : 0; mine.head_seds = need_head ? a.first_seds_end : 0;
+            }
+        })) return;
+    if (!phase([&] { xch_->all_gather(r, &mine, sizeof(SlabAnchors), all.data()); })) return;
+    for (int rk = 0; rk < N; rk++) if (!all[rk].ok) { if (r == 0) no_anchor_ = true; return; }     // the same on every rank
+    if (r == 0) chains_ = N - 1;
+
+    // ---- 2. boundary columns: every rank contributes [tail_col, cols) and [0, head_end) of its slab (padded to the largest)
+    auto tail_cols = [&](int rk) { return all[rk].cols - all[rk].tail_col; };
+    u64 cap = 1;
+    for (int rk = 0; rk < N; rk++) cap = std::max(cap, S * (tail_cols(rk) + all[rk].head_end));
+    std::vector<uint8_t> buf(cap, 0), gathered((size_t)cap * N);
+    if (!phase([&] {
+            EDSX_HIP(hipSetDevice(me.device));
+            if (tail_cols(r)) me.slab.copy_columns(mine.tail_col, tail_cols(r), buf.data(), st);
+            if (mine.head_end) me.slab.copy_columns(0, mine.head_end, buf.data() + S * tail_cols(r), st);
+        })) return;
+    if (!phase([&] { xch_->all_gather(r, buf.data(), cap, gathered.data()); })) return;
+
+    // ---- 3. the boundary r | r+1, recomputed by rank r
+    std::vector<uint8_t> extra_e, extra_s;
+    if (r + 1 < N) {
+        if (!phase([&] {
+                EDSX_HIP(hipSetDevice(me.device));
+                const u64 wl = tail_cols(r), wr = all[r + 1].head_end, width = wl + wr;
+                const uint8_t* left = gathered.data() + (size_t)r * cap;
+                const uint8_t* right = gathered.data() + (size_t)(r + 1) * cap + S * tail_cols(r + 1);
+                std::vector<uint8_t> mini(S * (width + 4));
+                for (u64 s = 0; s < S; s++) {
+                    uint8_t* d = mini.data() + s * (width + 4);
+                    d[0] = '>'; d[1] = 'r'; d[2] = '\n'; d += 3;
+                    std::memcpy(d, left + s * wl, wl); d += wl;
+                    std::memcpy(d, right + s * wr, wr); d += wr;
+                    *d = '\n';
+                }
+                me.d_mini.ensure(mini.size() + 16);
+                EDSX_HIP(hipMemcpyAsync(me.d_mini.ptr, mini.data(), mini.size(), hipMemcpyHostToDevice, st));
+                uint64_t e2 = 0, q2 = 0;
+                me.mini.plan(me.d_mini.as<uint8_t>(), mini.size(), l, st, &e2, &q2);
+                DevBuf oe, oq;
+                oe.ensure(e2 + 16); oq.ensure(q2 + 16);
+                me.mini.emit(oe.as<uint8_t>(), oq.as<uint8_t>(), st);
+                extra_e.resize(e2); extra_s.resize(q2);
+                EDSX_HIP(hipMemcpyAsync(extra_e.data(), oe.ptr, e2, hipMemcpyDeviceToHost, st));
+                EDSX_HIP(hipMemcpyAsync(extra_s.data(), oq.ptr, q2, hipMemcpyDeviceToHost, st));
+                EDSX_HIP(hipStreamSynchronize(st));
+            })) return;
+    } else if (!phase([] {})) return;
+
+    // ---- 4. piece sizes, offsets, the output buffers; 5. every rank writes its piece at its offset
+    const u64 elo = mine.head_eds, ehi = mine.tail_eds, slo = mine.head_seds, shi = mine.tail_seds;
+    std::vector<u64> sizes(2 * (size_t)N);
+    const u64 my[2] = {(ehi - elo) + extra_e.size(), (shi - slo) + extra_s.size()};
+    if (!phase([&] { xch_->all_gather(r, my, sizeof(my), sizes.data()); })) return;
+    u64 eoff = 0, soff = 0, etot = 0, stot = 0;
+    for (int rk = 0; rk < N; rk++) {
+        if (rk < r) { eoff += sizes[2 * rk]; soff += sizes[2 * rk + 1]; }
+        etot += sizes[2 * rk]; stot += sizes[2 * rk + 1];
+    }
+    if (!phase([&] { if (r == 0) { eds.take(etot); seds.take(stot); } })) return;
+    phase([&] {
+        EDSX_HIP(hipSetDevice(me.device));
+        if (ehi > elo) PinnedDownload::copy(eds.data + eoff, me.d_eds.as<uint8_t>() + elo, ehi - elo, st);
+        if (shi > slo) PinnedDownload::copy(seds.data + soff, me.d_seds.as<uint8_t>() + slo, shi - slo, st);
+        if (!extra_e.empty()) std::memcpy(eds.data + eoff + (ehi - elo), extra_e.data(), extra_e.size());
+        if (!extra_s.empty()) std::memcpy(seds.data + soff + (shi - slo), extra_s.data(), extra_s.size());
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Column batches on ONE GPU (edsx_msa_transform_batched, and what edsx_msa_transform falls back to when an alignment and
+// its tables do not fit the device): the slabs of the multi-GPU path one after the other through one pipeline.  The
+// working set is that of one slab (image, variant columns, records, tables); every slab's text goes to the host as soon
+// as it is written, the boundaries are stitched at the end exactly as between ranks - but the boundary columns come
+// straight from the host image, and the pieces are put together with host copies.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// rows x columns [g0, g1) of the host image as a one-line-per-row alignment (">r\n" + the columns + "\n")
+void host_mini_image(const uint8_t* fasta, const MsaLayout& lay, u64 g0, u64 g1, std::vector<uint8_t>& out)
+{
+    const u64 S = lay.start.size(), w = g1 - g0;
+    out.resize(S * (w + 4));
+    for (u64 s = 0; s < S; s++) {
+        uint8_t* d = out.data() + s * (w + 4);
+        d[0] = '>'; d[1] = 'r'; d[2] = '\n'; d += 3;
+        const uint8_t* row = fasta + lay.start[s];
+        if (lay.lw == 0) { std::memcpy(d, row + g0, w); d += w; }
+        else
+            for (u64 c = g0; c < g1;) {
+                const u64 in_line = c % lay.lw, take = std::min<u64>(lay.lw - in_line, g1 - c);
+                std::memcpy(d, row + c + c / lay.lw, take);
+                d += take; c += take;
+            }
+        *d = '\n';
+    }
+}
+
+} // namespace
+
+bool msa_transform_batched(const BatchResources& R, const uint8_t* fasta, const MsaLayout& lay, uint32_t l, int K,
+                           HostBytes& eds, HostBytes& seds, hipStream_t st)
+{
+    const u64 L = lay.L;
+    if (!lay.ok || K < 2 || L < 2ull * (u64)K || L / (u64)K < 4ull * l) return false;
+    std::vector<u64> c0(K + 1);
+    for (int r = 0; r <= K; r++) c0[r] = L * (u64)r / (u64)K;
+    std::vector<HostBytes> pe(K), ps(K);
+    std::vector<SlabEdges> edges(K);
+    std::vector<SlabAnchors> anch(K);
+
+    // ---- 1. every slab: image -> HBM, plan, emit, descriptors, text -> host
+    for (int r = 0; r < K; r++) {
+        const u64 ncols = c0[r + 1] - c0[r];
+        const RowImage ri = upload_row_image(fasta, lay, c0[r], c0[r + 1], *R.d_img, *R.host_tmp, st);
+        uint64_t E = 0, Q = 0;
+        R.slab->plan(R.d_img->as<uint8_t>(), ri.bytes, l, st, &E, &Q);
+        R.d_eds->ensure(E + 16); R.d_seds->ensure(Q + 16);
+        R.slab->emit(R.d_eds->as<uint8_t>(), R.d_seds->as<uint8_t>(), st);
+        if (l == 0) {
+            const MsaPipeline::Edges e = R.slab->edge_info(st);
+            edges[r] = SlabEdges{e.nseg, ncols, E, Q, e.fvar, e.fcols, e.feds, e.fseds, e.lvar, e.lcols, e.leds, e.lseds};
+        } else {
+            const MsaPipeline::Anchors a = R.slab->anchor_info(l, st);
+            SlabAnchors& m = anch[r];
+            m = SlabAnchors{};
+            m.cols = ncols; m.eds_bytes = E; m.seds_bytes = Q;
+            const bool need_head = r > 0, need_tail = r + 1 < K;
+            bool ok = a.found != 0;
+            if (ok && need_head && need_tail) ok = a.first_seg < a.last_seg;
+            if (ok && need_head) ok = a.first_end <= ANCHOR_MAX_COLS;
+            if (ok && need_tail) ok = ncols - a.last_col <= ANCHOR_MAX_COLS;
+            if (!ok) return false;                            // no anchors: not batched
+            m.ok = 1;
+            m.tail_col = need_tail ? a.last_col : ncols; m.tail_eds = need_tail ? a.last_eds : E; m.tail_seds = need_tail ? a.last_seds : Q;
+            m.head_end = need_head ? a.first_end : 0; m.head_eds = need_head ? a.first_eds_end : 0; m.head_seds = need_head ? a.first_seds_end : 0;
+        }
+        pe[r].take(E); ps[r].take(Q);
+        PinnedDownload::copy(pe[r].data, R.d_eds->ptr, E, st);
+        PinnedDownload::copy(ps[r].data, R.d_seds->ptr, Q, st);
+    }
+
+    // ---- 2. boundaries: which bytes of every slab's text stay, and the text recomputed behind them
+    std::vector<u64> elo(K), ehi(K), slo(K), shi(K);
+    std::vector<std::vector<uint8_t>> xe(K), xs(K);
+    std::vector<uint8_t> mini;
+    auto recompute = [&](int owner, u64 g0, u64 g1) {
+        host_mini_image(fasta, lay, g0, g1, mini);
+        R.d_mini->ensure(mini.size() + 16);
+        EDSX_HIP(hipMemcpyAsync(R.d_mini->ptr, mini.data(), mini.size(), hipMemcpyHostToDevice, st));
+        uint64_t e2 = 0, q2 = 0;
+        R.mini->plan(R.d_mini->as<uint8_t>(), mini.size(), l, st, &e2, &q2);
+        DevBuf oe, oq;
+        oe.ensure(e2 + 16); oq.ensure(q2 + 16);
+        R.mini->emit(oe.as<uint8_t>(), oq.as<uint8_t>(), st);
+        const size_t a = xe[owner].size(), b = xs[owner].size();
+        xe[owner].resize(a + e2); xs[owner].resize(b + q2);
+        EDSX_HIP(hipMemcpyAsync(xe[owner].data() + a, oe.ptr, e2, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipMemcpyAsync(xs[owner].data() + b, oq.ptr, q2, hipMemcpyDeviceToHost, st));
+        EDSX_HIP(hipStreamSynchronize(st));
+    };
+    if (l == 0) {
+        const StitchPlan plan = plan_stitch(edges);
+        for (int r = 0; r < K; r++) {
+            const SlabEdges& e = edges[r];
+            const SlabAction& a = plan.actions[r];
+            elo[r] = a.front_eds; ehi[r] = e.eds_bytes - std::min(e.eds_bytes, a.back_eds);
+            slo[r] = a.front_seds; shi[r] = e.seds_bytes - std::min(e.seds_bytes, a.back_seds);
+            if (ehi[r] < elo[r]) ehi[r] = elo[r];
+            if (shi[r] < slo[r]) shi[r] = slo[r];
+        }
+        for (const SlabChain& ch : plan.chains)
+            if (ch.variant)
+                recompute(ch.first, c0[ch.first] + edges[ch.first].cols - edges[ch.first].last_cols, c0[ch.last] + edges[ch.last].first_cols);
+    } else {
+        for (int r = 0; r < K; r++) {
+            elo[r] = anch[r].head_eds; ehi[r] = anch[r].tail_eds; slo[r] = anch[r].head_seds; shi[r] = anch[r].tail_seds;
+            if (r + 1 < K) recompute(r, c0[r] + anch[r].tail_col, c0[r + 1] + anch[r + 1].head_end);
+        }
+    }
+
+    // ---- 3. the pieces in order
+    u64 etot = 0, stot = 0;
+    for (int r = 0; r < K; r++) { etot += (ehi[r] - elo[r]) + xe[r].size(); stot += (shi[r] - slo[r]) + xs[r].size(); }
+    eds.take(etot); seds.take(stot);
+    u64 eo = 0, so = 0;
+    for (int r = 0; r < K; r++) {
+        std::memcpy(eds.data + eo, pe[r].data + elo[r], ehi[r] - elo[r]); eo += ehi[r] - elo[r];
+        std::memcpy(seds.data + so, ps[r].data + slo[r], shi[r] - slo[r]); so += shi[r] - slo[r];
+        if (!xe[r].empty()) { std::memcpy(eds.data + eo, xe[r].data(), xe[r].size()); eo += xe[r].size(); }
+        if (!xs[r].empty()) { std::memcpy(seds.data + so, xs[r].data(), xs[r].size()); so += xs[r].size(); }
+    }
+    return true;
 }
 
 } // namespace edsx

@@ -6,7 +6,8 @@
 // if it were a whole alignment, and the runs that cross a slab boundary are repaired with KB-sized exchanges
 // (SURVEY §8(e)): an all-gather of twelve numbers per rank (the edge descriptors), and - only when a VARIANT run
 // crosses a boundary - an all-gather of the raw boundary columns, from which the left-most rank recomputes that
-// segment.  The exchanges are ncclAllGather calls on one communicator per rank (RcclExchange); LocalExchange moves the
+// segment.  With a context length l > 0 every boundary is recomputed between the nearest standalone common runs of at
+// least l columns on either side (run_rank_leds in multi_gpu.hip).  The exchanges are ncclAllGather calls on one communicator per rank (RcclExchange); LocalExchange moves the
 // same bytes between the rank threads directly and exists so that the whole path can be tested with several contexts
 // sharing ONE GPU (RCCL does not run two ranks on one device).
 #pragma once
@@ -43,6 +44,13 @@ struct RowImage { u64 rows = 0, cols = 0, hdr0 = 0, hdr = 0, bytes = 0; };
 RowImage upload_row_image(const uint8_t* fasta, const MsaLayout& lay, u64 c0, u64 c1, DevBuf& d_img, std::vector<uint8_t>& host_tmp,
                           hipStream_t st);
 
+// msa2eds in K column batches on one GPU (working set of one slab; see multi_gpu.hip).  false: not batched - the image is
+// not a plain uniform alignment, the batches would be too narrow, or (l > 0) a slab has no standalone common runs to
+// anchor the stitch on; nothing has been written to eds / seds then.
+struct BatchResources { MsaPipeline* slab; MsaPipeline* mini; DevBuf* d_img; DevBuf* d_eds; DevBuf* d_seds; DevBuf* d_mini; std::vector<uint8_t>* host_tmp; };
+bool msa_transform_batched(const BatchResources& R, const uint8_t* fasta, const MsaLayout& lay, uint32_t l, int K,
+                           HostBytes& eds, HostBytes& seds, hipStream_t st);
+
 // all ranks call with `bytes` bytes each; `all` receives world * bytes bytes in rank order
 class Exchange {
 public:
@@ -68,7 +76,8 @@ class MultiMsa {
 public:
     MultiMsa(const std::vector<int>& devices, bool use_rccl);
     ~MultiMsa();
-    // msa2eds (context length 0: column slabs; > 0 or an odd file: rank 0 transforms the whole image)
+    // msa2eds: column slabs (context length > 0: stitched between standalone common runs); an odd file, or an l-EDS
+    // without such runs near the slab ends: rank 0 transforms the whole image
     void transform(const uint8_t* fasta, size_t n, uint32_t context_len, HostBytes& eds, HostBytes& seds);
     int world() const { return (int)devices_.size(); }
     bool partitioned() const { return partitioned_; }
@@ -77,11 +86,13 @@ public:
 private:
     struct Rank;
     void run_rank(int r, const uint8_t* fasta, size_t n, const MsaLayout& lay, HostBytes& eds, HostBytes& seds);
+    void run_rank_leds(int r, const uint8_t* fasta, const MsaLayout& lay, uint32_t l, HostBytes& eds, HostBytes& seds);
     std::vector<int> devices_;
     std::vector<std::unique_ptr<Rank>> ranks_;
     std::unique_ptr<Exchange> xch_;
     std::unique_ptr<RankBarrier> bar_;
     bool partitioned_ = false;
+    bool no_anchor_ = false;             // l > 0: some slab has no standalone common runs to anchor the stitch on
     int chains_ = 0;
     // shared between the rank threads of one call
     std::vector<u64> piece_e_, piece_s_;

@@ -21,6 +21,7 @@ int main(int argc, char** argv)
         opts.add("sources", 's', true, false, "Output source file (default: <output>.seds)");
         opts.add("context-length", 'l', true, false, "Create l-EDS with minimum context length (0 = regular EDS)");
         opts.add("gpus", 'g', true, false, "Spread the alignment's columns over this many GPUs of the node (RCCL boundary stitch; default 1)");
+        opts.add("batches", 'b', true, false, "Transform in this many column batches, one after the other on the GPU (bounds device memory; default: one piece, batches only when the alignment does not fit)");
         opts.parse(argc, argv);
         if (opts.has("help")) {
             std::cout << "msa2eds - Transform MSA (Multiple Sequence Alignment) to EDS\n\n" << opts.usage() << "\n"
@@ -32,7 +33,8 @@ int main(int argc, char** argv)
                          "  msa2eds -i alignment.msa            # alignment.eds + alignment.seds\n"
                          "  msa2eds -i alignment.msa -l 10      # alignment_l10.leds + alignment_l10.seds\n"
                          "  msa2eds -i alignment.msa -o output.eds -s output.seds\n"
-                         "  msa2eds -i alignment.msa --gpus 8   # column slabs on GPUs 0..7, stitched over RCCL\n\n"
+                         "  msa2eds -i alignment.msa --gpus 8   # column slabs on GPUs 0..7, stitched over RCCL\n"
+                         "  msa2eds -i alignment.msa --batches 4  # a quarter of the columns on the GPU at a time\n\n"
                          "IMPLEMENTATION:\n"
                          "  The alignment is transformed on an AMD MI355X (gfx950) through libedsx.\n\n";
             tool::print_performance(timer);
@@ -77,10 +79,21 @@ int main(int argc, char** argv)
             if (rc != EDSX_OK) throw std::runtime_error(what);
             std::cout << "  GPUs: " << ngpu << (parted ? " (column slabs, " + std::to_string(chains) + " boundary segments stitched)"
                                                          : std::string(ngpu > 1 ? " (not partitioned: one GPU transforms the file)" : "")) << "\n";
+        } else if (opts.has("batches")) {
+            const unsigned long nb = opts.get_unsigned("batches", 1);
+            if (nb == 0 || nb > 4096) throw std::runtime_error("--batches must be between 1 and 4096");
+            edsx_ctx* ctx = detail::context();
+            int used = 0;
+            const int rc = edsx_msa_transform_batched(ctx, msa_in.data(), msa_in.size(), context_length, static_cast<int>(nb),
+                                                      &eds_out.b, &seds_out.b, &used);
+            if (rc != EDSX_OK) detail::throw_status(rc, ctx);
+            std::cout << "  Column batches: " << used << (used == 1 && nb > 1 ? " (not cut: one piece)" : "") << "\n";
         } else {
             edsx_ctx* ctx = detail::context();
             const int rc = edsx_msa_transform(ctx, msa_in.data(), msa_in.size(), context_length, &eds_out.b, &seds_out.b);
             if (rc != EDSX_OK) detail::throw_status(rc, ctx);
+            if (edsx_msa_last_batches(ctx) > 1)
+                std::cout << "  Column batches: " << edsx_msa_last_batches(ctx) << " (the alignment does not fit the device in one piece)\n";
         }
 
         std::filesystem::path eds_path, seds_path;

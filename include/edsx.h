@@ -65,6 +65,17 @@ const char* edsx_version(void);
  * Output bytes are identical to the std::string pair the reference returns. */
 int edsx_msa_transform(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint32_t context_len,
                        edsx_buf* eds, edsx_buf* seds);
+/* The same in `batches` column batches, one after the other on the context's GPU: the device holds one batch (its
+ * image, variant columns, records and tables) at a time, every batch's text goes to the host as it is written, and the
+ * segments that cross a batch boundary are stitched as between the GPUs of edsx_msa_transform_multi.  Output is
+ * byte-identical to edsx_msa_transform, which falls back to this (2, 4, 8 ... batches) when an alignment and its tables
+ * do not fit the device in one piece.  An input that cannot be cut (not a plain uniform alignment, batches narrower than
+ * 4 * context_len columns, or - context_len > 0 - a batch without a common run of context_len columns near both ends)
+ * is transformed in one piece.  *batches_used (may be NULL) receives the number of batches taken (1: one piece). */
+int edsx_msa_transform_batched(edsx_ctx* ctx, const uint8_t* msa, size_t msa_size, uint32_t context_len, int batches,
+                               edsx_buf* eds, edsx_buf* seds, int* batches_used);
+/* column batches the last successful edsx_msa_transform / _batched of this context took (1: one piece; 0: none yet) */
+int edsx_msa_last_batches(const edsx_ctx* ctx);
 
 /* EDS (+ optional sEDS) -> l-EDS.  seds == NULL => CARTESIAN, else LINEAR.
  * compact != 0 => COMPACT brackets (the CLI default), else FULL.  Outputs end in '\n' like
@@ -193,8 +204,9 @@ int edsx_msa_locate_segment(edsx_ctx* ctx, uint64_t col, uint64_t* seg, uint64_t
  * GPU transforms its slab, and the segments that cross a slab boundary are stitched with KB-sized all-gathers:
  * ncclAllGather over RCCL (use_rccl = 1: one distinct device per rank), or an in-process exchange between the rank
  * threads (use_rccl = 0: ranks may share a device - rehearsals and tests on a one-GPU box).  Output is byte-identical
- * to edsx_msa_transform.  context_len > 0 and files that are not plain uniform alignments are transformed by rank 0
- * alone. */
+ * to edsx_msa_transform.  With context_len > 0 every boundary is recomputed between the nearest common runs of at
+ * least context_len columns on either side; files that are not plain uniform alignments, and l-EDS slabs without such
+ * runs near their ends, are transformed by rank 0 alone. */
 typedef struct edsx_multi edsx_multi;
 int  edsx_multi_create(const int* device_ids, int n, int use_rccl, edsx_multi** out);
 void edsx_multi_destroy(edsx_multi* m);

@@ -339,6 +339,9 @@ def test_device_tokeniser_hands_odd_text_to_the_host(ctx):
         (b"{A,C", None),                     # unterminated
         (b"{A,C}{G}", b"{1}{2}"),            # source count differs from the cardinality
         (b"{A,C}{G}", b"{1}{}{0}"),          # empty path set
+        (b"{A,C}{G}", b"{1}{,,}{0}"),        # ... of commas only
+        (b"{A,C}{G}", b"{1}{2}}{0}"),        # stray brace in the sources
+        (b"{A,C}{G}", b"{1}{2}{{0}"),
         (b"{A,C}{G}", b"{1}{2x}{0}"),        # character that does not belong
         (b"{A,C}{G}", b"{1}{99999999999}{0}"),
         (b"", None), (b"\n", None),
@@ -365,6 +368,103 @@ def test_device_tokeniser_hands_odd_text_to_the_host(ctx):
         got.pop("code", None)
         assert got == want, (eds, seds)
         assert ctx.leds_tokenised_on_device(), (eds, seds)
+
+
+def test_device_tokeniser_block_and_thread_boundaries(ctx):
+    """The device tokenisers work on 4 KB blocks of 256 x 16 bytes: every brace, comma, bare-run start and id of a text is
+    moved across those boundaries (a bare prefix of p letters in the .eds, an id with p leading zeros in the .seds shift
+    everything behind them by p), and the result is compared with the host tokenisers and the oracle."""
+    rng = random.Random(4096)
+    syms = []
+    for _ in range(900):
+        k = rng.choice([1, 1, 2, 3, 4])
+        strs = ["".join(rng.choice("ACGT") for _ in range(rng.choice([0, 1, 2, 5, 17]))) for _ in range(k)]
+        if k == 1 and not strs[0]:
+            strs[0] = "A"
+        syms.append(strs)
+    body = "".join("{" + ",".join(x) + "}" for x in syms)
+    # (the first string of every symbol is on all paths, so no merge comes out empty)
+    sbody = "".join("{" + (",".join(str(rng.randint(1, 1500)) for _ in range(rng.randint(1, 3))) if j else "0") + "}"
+                    for x in syms for j in range(len(x)))
+    assert len(body) > 3 * 4096 and len(sbody) > 3 * 4096
+    shifts = list(range(1, 18)) + [31, 32, 33] + list(range(4085, 4108, 2)) + [8191, 8192, 8193]
+
+    def both_tokenisers(fn):
+        got = fn()
+        assert ctx.leds_tokenised_on_device()
+        os.environ["EDSX_HOST_TOKENIZER"] = "1"
+        try:
+            host = fn()
+            assert not ctx.leds_tokenised_on_device()
+        finally:
+            del os.environ["EDSX_HOST_TOKENIZER"]
+        return got, host
+
+    for p_ in shifts:
+        eds = ("A" * p_ + body).encode()
+        seds = ("{" + "0" * p_ + "}" + sbody).encode()
+        got, host = both_tokenisers(lambda: _run(ctx, eds, seds, 4, True))
+        assert got == host, p_
+        # (without sources the merge is CARTESIAN and its output explodes: the tokenisers alone, through the statistics call)
+        got, host = both_tokenisers(lambda: ctx.eds_stats(eds + b"\n", None, 4))
+        assert got == host, p_
+        if p_ in (1, 4097):
+            try:
+                w = o.merge(eds, seds, 4, True)
+                want = {"out": w[0].decode(), "seds_out": w[1].decode()}
+            except o.OracleError as ex:
+                want = {"error": str(ex)}
+            g = _run(ctx, eds, seds, 4, True)
+            g.pop("code", None)
+            assert g == want, p_
+    # a text that is rejected at the very end (after the arrays were filled) still takes the host path
+    import edsparser_amd
+    with pytest.raises(edsparser_amd.EdsxError):
+        ctx.eds_stats((body + "{A").encode(), None, 4)
+    assert not ctx.leds_tokenised_on_device()
+
+
+def test_deep_tree_fallback_paths():
+    """Final text when the merge trees do not fit the stacks: k_fin_write's LDS stack overflows -> the batch goes to the
+    serial walk -> after more rounds than its own stack holds, that walk uses a per-string stack in HBM sized by the number
+    of rounds.  Real inputs need trees deeper than 96 for this; `libedsx_smallstacks.so` (built by edsparser_amd.build for
+    the tests only: 256-entry LDS stack, 2-entry register stack) takes ordinary campaign inputs down that path.  A child
+    process loads it through EDSX_LIB, so the suite's own library stays the product build."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "edsparser_amd", "libedsx_smallstacks.so")
+    assert os.path.exists(lib), "python -m edsparser_amd.build builds it"
+    code = """
+import random, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import edsparser_amd, oracle_lib as o
+from merge_cases import campaign_eds
+ctx = edsparser_amd.Context(0)
+rng = random.Random(96)
+ran = merged = 0
+for it in range(220):
+    eds, seds, l, compact, desc = campaign_eds(rng)
+    if desc[-1] > 100000:
+        continue
+    try:
+        w = o.merge(eds, seds, l, compact)
+        want = (w[0], w[1])
+    except o.OracleError as ex:
+        want = str(ex)
+    try:
+        got = ctx.leds_merge(eds, seds, l, compact)
+    except edsparser_amd.EdsxError as ex:
+        got = ex.message
+    assert got == want, (it, desc, l, compact)
+    ran += 1
+    merged += isinstance(want, tuple) and want[0].strip() != eds.strip()
+print("ran", ran, "merged", merged)
+assert ran > 150 and merged > 60
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, EDSX_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_large_downloads_every_size_remainder(ctx):

@@ -446,3 +446,57 @@ def test_host_call_uploads_large_alignments_as_an_aligned_row_image(ctx):
     with pytest.raises(edsparser_amd.EdsxError) as ei:
         ctx.msa_transform(bytes(bad), 0)
     assert "Invalid MSA" in str(ei.value)
+
+
+@pytest.mark.parametrize("K", [2, 3, 7])
+def test_column_batches_equal_the_single_call(ctx, K):
+    """edsx_msa_transform_batched: K column batches one after the other through one pipeline, stitched like the slabs of
+    the multi-GPU path (boundary columns straight from the host image).  l = 0 and l-EDS, one-line and wrapped rows."""
+    rng = random.Random(900 + K)
+    cut = whole = 0
+    for i in range(40):
+        lw = rng.choice([None, None, 7, 60])
+        l = rng.choice([0, 0, 1, 3, 8])
+        msa = random_msa(rng, S=rng.randint(2, 9), L=rng.randint(40 * K, 1200), lw=lw, trailing_newline=rng.random() < 0.7,
+                         p_var=rng.choice([0.01, 0.05, 0.2]))
+        e, s, used = ctx.msa_transform_batched(msa, l, K)
+        assert (e, s) == o.msa(msa, l), (i, l, msa)
+        assert used in (1, K)
+        cut += used == K
+        whole += used == 1
+    assert cut >= 25
+    # not an alignment the geometry walk accepts: one piece, the transform words the error
+    import edsparser_amd
+    with pytest.raises(edsparser_amd.EdsxError) as ei:
+        ctx.msa_transform_batched(b">a\nACGT\n>b\nACG\n", 0, K)
+    assert ei.value.code == 2
+
+
+def test_alignment_that_does_not_fit_in_one_piece_is_batched(ctx):
+    """edsx_msa_transform falls back to column batches when the device runs out of memory: most of the free HBM is taken
+    away, then an alignment whose tables need more than what is left (but whose batches do not) must still come out
+    byte-equal to the run with the memory available."""
+    import torch
+    import edsparser_amd
+    S, L = 64, 24_000_000
+    n = edsparser_amd.synth_size(S, L)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    ctx.msa_synth_device(buf.data_ptr(), n, S, L, seed=5)
+    torch.cuda.synchronize()
+    host = bytes(buf.cpu().numpy())
+    del buf
+    want = ctx.msa_transform(host, 0)
+    c2 = edsparser_amd.Context(0)                                   # a fresh context: nothing cached from the run above
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    keep_free = 3 << 30                                             # the whole run needs ~5 GB (image 1.5 GB + 84 B per column of tables)
+    hog = torch.empty(max(0, free - keep_free), dtype=torch.uint8, device="cuda:0")
+    try:
+        got = c2.msa_transform(host, 0)
+        batches = c2.msa_last_batches()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+        c2.close()
+    assert got == want
+    assert batches >= 2
