@@ -41,6 +41,11 @@ class MsaInfo(ctypes.Structure):
                  "n_slow_segments")]
 
 
+class MsaAnchors(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("n_segments", "found", "first_seg", "last_seg", "last_col", "last_eds_bytes",
+                                               "last_seds_bytes", "first_end", "first_eds_end", "first_seds_end")]
+
+
 class MsaEdges(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in
                 ("n_segments", "first_is_variant", "first_cols", "first_eds_bytes", "first_seds_bytes",
@@ -101,6 +106,7 @@ def load_library():
     lib.edsx_msa_emit_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.edsx_msa_last_info.argtypes = [ctypes.c_void_p, P(MsaInfo)]
     lib.edsx_msa_edge_info.argtypes = [ctypes.c_void_p, P(MsaEdges)]
+    lib.edsx_msa_anchor_info.argtypes = [ctypes.c_void_p, ctypes.c_uint64, P(MsaAnchors)]
     lib.edsx_msa_copy_columns.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
     lib.edsx_msa_locate_segment.argtypes = [ctypes.c_void_p, ctypes.c_uint64] + [P(ctypes.c_uint64)] * 4
     lib.edsx_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -346,6 +352,12 @@ class Context:
         e = MsaEdges()
         self._check(self._lib.edsx_msa_edge_info(self._h, ctypes.byref(e)))
         return {n: int(getattr(e, n)) for n, _ in MsaEdges._fields_}
+
+    def msa_anchor_info(self, min_cols):
+        """First / last common segment of at least min_cols columns of the planned alignment (see edsx.h)."""
+        a = MsaAnchors()
+        self._check(self._lib.edsx_msa_anchor_info(self._h, min_cols, ctypes.byref(a)))
+        return {n: int(getattr(a, n)) for n, _ in MsaAnchors._fields_}
 
     def msa_copy_columns(self, col0, ncols, n_rows):
         buf = ctypes.create_string_buffer(n_rows * ncols)

@@ -186,6 +186,17 @@ int edsx_msa_edge_info(edsx_ctx* ctx, edsx_msa_edges* out)
     });
 }
 
+int edsx_msa_anchor_info(edsx_ctx* ctx, uint64_t min_cols, edsx_msa_anchors* out)
+{
+    return guarded(ctx, [&] {
+        if (!out) throw ParamError("null argument");
+        const MsaPipeline::Anchors a = ctx->msa.anchor_info(min_cols, nullptr);
+        out->n_segments = a.nseg; out->found = a.found; out->first_seg = a.first_seg; out->last_seg = a.last_seg;
+        out->last_col = a.last_col; out->last_eds_bytes = a.last_eds; out->last_seds_bytes = a.last_seds;
+        out->first_end = a.first_end; out->first_eds_end = a.first_eds_end; out->first_seds_end = a.first_seds_end;
+    });
+}
+
 int edsx_msa_copy_columns(edsx_ctx* ctx, uint64_t col0, uint64_t ncols, uint8_t* host_out)
 {
     return guarded(ctx, [&] {

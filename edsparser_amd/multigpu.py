@@ -371,21 +371,110 @@ def msa_slab_image(msa, layout, c0, c1):
     return bytes(out)
 
 
-class MsaSharder:
-    """Column-slab partition of an alignment FILE for one rank (context length 0).  slab_fn(image, n_rows, ncols) ->
-    (eds, seds, SlabEdges, get_columns) transforms a slab (the C ABI on the GPU, the oracle in the CPU tests);
-    mini_fn(image) -> (eds, seds) transforms the few boundary columns of a variant run that crosses a cut."""
+ANCHOR_MAX_COLS = 1 << 16
 
-    def __init__(self, rank, world, dist, slab_fn, mini_fn, whole_fn, device=None):
+
+def leds_anchor_fields(a, rank, world, ncols, eds_bytes, seds_bytes):
+    """What a rank tells the others about its l-EDS slab (see MsaSharder): [ok, tail_col, tail_eds, tail_seds, head_end,
+    head_eds, head_seds, ncols].  `a` is edsx_msa_anchor_info of the slab: its first and last common segment of at least
+    l columns.  A middle slab needs two distinct anchors, the first slab only a last one, the last slab only a first one;
+    an anchor further than ANCHOR_MAX_COLS from its end of the slab is not used (the boundary zone travels as raw
+    columns)."""
+    need_head, need_tail = rank > 0, rank + 1 < world
+    ok = bool(a["found"])
+    if ok and need_head and need_tail:
+        ok = a["first_seg"] < a["last_seg"]
+    if ok and need_head:
+        ok = a["first_end"] <= ANCHOR_MAX_COLS
+    if ok and need_tail:
+        ok = ncols - a["last_col"] <= ANCHOR_MAX_COLS
+    if not ok:
+        return [0, 0, 0, 0, 0, 0, 0, ncols]
+    return [1,
+            a["last_col"] if need_tail else ncols, a["last_eds_bytes"] if need_tail else eds_bytes,
+            a["last_seds_bytes"] if need_tail else seds_bytes,
+            a["first_end"] if need_head else 0, a["first_eds_end"] if need_head else 0, a["first_seds_end"] if need_head else 0,
+            ncols]
+
+
+class MsaSharder:
+    """Column-slab partition of an alignment FILE for one rank.  slab_fn(image, n_rows, ncols) ->
+    (eds, seds, SlabEdges, get_columns) transforms a slab (the C ABI on the GPU, the oracle in the CPU tests);
+    mini_fn(image) -> (eds, seds) transforms the few boundary columns of a variant run that crosses a cut.
+    Context length l > 0 (leds_fn / mini_leds_fn given): an l-EDS joins variant runs with the common runs of fewer than
+    l columns between them, and only a common run of at least l columns - or one at either end of the alignment - stands
+    alone (msa_transforms.cpp:133-190).  A slab transformed on its own applies the "at either end" clause at its own
+    ends, so its text is the alignment's text exactly between its first and its last standalone run of >= l columns (its
+    anchors).  Every boundary is therefore recomputed from the last anchor of the left slab to the first anchor of the
+    right one (both included), by the left rank: leds_fn(image, n_rows, ncols, l) -> (eds, seds, anchor_info,
+    get_columns), mini_leds_fn(image, l) -> (eds, seds).  Exchanges: 8 int64 per rank, the raw boundary columns as one
+    padded uint8 payload per rank, 2 int64 per rank.  A slab without usable anchors sends the file to rank 0."""
+
+    def __init__(self, rank, world, dist, slab_fn, mini_fn, whole_fn, device=None, leds_fn=None, mini_leds_fn=None):
         self.rank, self.world, self.dist = rank, world, dist
         self.slab_fn, self.mini_fn, self.whole_fn, self.device = slab_fn, mini_fn, whole_fn, device
+        self.leds_fn, self.mini_leds_fn = leds_fn, mini_leds_fn
         self.comm = TensorComm(dist, world, device)
+
+    def _run_leds(self, msa, layout, l):
+        """-> the rank's piece, or None when some slab has no usable anchors (decided by every rank alike)"""
+        rank, world = self.rank, self.world
+        starts, _draw, _lw, L = layout
+        n_rows = len(starts)
+        c0, c1 = L * rank // world, L * (rank + 1) // world
+        ncols = c1 - c0
+        eds, seds, a, get_columns, err = b"", b"", None, None, None
+        try:
+            eds, seds, a, get_columns = self.leds_fn(msa_slab_image(msa, layout, c0, c1), n_rows, ncols, l)
+        except Exception as ex:                                    # noqa: BLE001 - raised on every rank below
+            err = ex
+        self.comm.raise_if_any_failed(err)
+        allv = self.comm.ints(leds_anchor_fields(a, rank, world, ncols, len(eds), len(seds)))
+        if not all(v[0] for v in allv):
+            return None
+        _ok, tail_col, tail_eds, tail_seds, head_end, head_eds, head_seds, _n = allv[rank]
+        tail_w = [v[7] - v[1] for v in allv]
+        # boundary columns: [tail_col, ncols) and [0, head_end) of every slab, row-major blocks
+        payload, err = b"", None
+        try:
+            if tail_w[rank]:
+                payload += get_columns(tail_col, tail_w[rank])
+            if head_end:
+                payload += get_columns(0, head_end)
+        except Exception as ex:                                    # noqa: BLE001
+            err = ex
+        self.comm.raise_if_any_failed(err)
+        blocks = self.comm.payloads(payload)
+        extra_e, extra_s, err = b"", b"", None
+        if rank + 1 < world:
+            try:
+                wl, wr = tail_w[rank], allv[rank + 1][4]
+                left = blocks[rank][:n_rows * wl]
+                right = blocks[rank + 1][n_rows * tail_w[rank + 1]:n_rows * (tail_w[rank + 1] + wr)]
+                mini = bytearray()
+                for r in range(n_rows):
+                    mini += b">r\n" + left[r * wl:(r + 1) * wl] + right[r * wr:(r + 1) * wr] + b"\n"
+                extra_e, extra_s = self.mini_leds_fn(bytes(mini), l)
+            except Exception as ex:                                # noqa: BLE001
+                err = ex
+        self.comm.raise_if_any_failed(err)
+        e = eds[head_eds:tail_eds] + extra_e
+        sd = seds[head_seds:tail_seds] + extra_s
+        sizes = self.comm.ints([len(e), len(sd)])
+        return {"eds": e, "seds": sd, "eds_offset": sum(v[0] for v in sizes[:rank]), "seds_offset": sum(v[1] for v in sizes[:rank]),
+                "eds_total": sum(v[0] for v in sizes), "seds_total": sum(v[1] for v in sizes), "partitioned": True}
 
     def run(self, msa, context_len=0):
         rank, world = self.rank, self.world
-        layout = msa_layout(msa) if context_len == 0 else None
+        layout = msa_layout(msa)
+        if context_len > 0 and layout is not None and world > 1:
+            if self.leds_fn is not None and layout[3] >= 2 * world and layout[3] // world >= 4 * context_len:
+                piece = self._run_leds(msa, layout, context_len)
+                if piece is not None:
+                    return piece
+            layout = None                                          # no anchors, narrow slabs: rank 0 alone
         if layout is None or layout[3] < 2 * world or world == 1:
-            # not partitioned (l-EDS boundaries look across runs, msa_transforms.cpp:133-190; odd files): rank 0 alone
+            # not partitioned (odd files; l-EDS slabs without standalone common runs near their ends): rank 0 alone
             eds, seds, err = b"", b"", None
             if rank == 0:
                 try:
@@ -427,8 +516,12 @@ def gpu_msa_sharder(ctx, mini_ctx, rank, world, dist, device=None):
                           last_is_variant=e["last_is_variant"], last_cols=e["last_cols"],
                           last_eds_bytes=e["last_eds_bytes"], last_seds_bytes=e["last_seds_bytes"])
         return eds, seds, edges, lambda c0, nc: ctx.msa_copy_columns(c0, nc, n_rows)
+    def leds_fn(image, n_rows, ncols, l):
+        eds, seds = ctx.msa_transform(image, l)
+        return eds, seds, ctx.msa_anchor_info(l), lambda c0, nc: ctx.msa_copy_columns(c0, nc, n_rows)
     return MsaSharder(rank, world, dist, slab_fn, lambda m: mini_ctx.msa_transform(m, 0),
-                      lambda m, l: ctx.msa_transform(m, l), device=device)
+                      lambda m, l: ctx.msa_transform(m, l), device=device, leds_fn=leds_fn,
+                      mini_leds_fn=lambda m, l: mini_ctx.msa_transform(m, l))
 
 
 # ======================================================================================================

@@ -188,6 +188,16 @@ typedef struct {
     uint64_t last_is_variant, last_cols, last_eds_bytes, last_seds_bytes;
 } edsx_msa_edges;
 int edsx_msa_edge_info(edsx_ctx* ctx, edsx_msa_edges* out);
+/* l-EDS slabs (context length l > 0): the first and the last common segment of at least min_cols columns of the planned
+ * alignment - the anchors between which a slab's text does not depend on its neighbours (msa_transforms.cpp:153).
+ * found = 0: there is none.  last_*: the last anchor's first column and the text offsets in front of it; first_*: the
+ * column behind the first anchor and the text offsets behind it. */
+typedef struct {
+    uint64_t n_segments, found, first_seg, last_seg;
+    uint64_t last_col, last_eds_bytes, last_seds_bytes;
+    uint64_t first_end, first_eds_end, first_seds_end;
+} edsx_msa_anchors;
+int edsx_msa_anchor_info(edsx_ctx* ctx, uint64_t min_cols, edsx_msa_anchors* out);
 /* Alignment columns [col0, col0+ncols) of every row of the planned alignment, row-major
  * (n_rows * ncols bytes) into a host buffer. */
 int edsx_msa_copy_columns(edsx_ctx* ctx, uint64_t col0, uint64_t ncols, uint8_t* host_out);

@@ -1,5 +1,5 @@
 """Randomized parity campaign against the oracle (run on the GPU box: python tests/campaign_msa.py <seed> <cases> [big]
-- `big`: row counts of the generic workgroup-per-segment kernels, 1025 .. 8192).
+- `big`: row counts of the generic workgroup-per-segment kernels, 1025 .. 8192; `huge`: 8193 .. 40000 rows, their tables in HBM).
 The suite runs a fixed slice of the same generators (test_randomized_campaign); logs of long runs are in profiles/."""
 import os, sys, random, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -8,11 +8,13 @@ ctx = edsparser_amd.Context(0)
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
+huge = len(sys.argv) > 3 and sys.argv[3] == "huge"
 rng = random.Random(seed)
 ALPH = ["ACGT", "ACGTN", "ACGTacgtN", "ACDEFGHIKLMNPQRSTVWY", "AC"]
 def gen(rng):
     S = rng.choice([2, 3, 5, 17, 33, 64, 65, 100, 130, 256, 257, 400, 513, 700, 960, 1000, 1024, 1025, 1100, rng.randint(2, 1200)])
     if big: S = rng.choice([1025, 1500, 2000, 2047, 2048, 2049, 2500, 3000, 4096, 5000, 8191, 8192, rng.randint(1025, 8192)])
+    if huge: S = rng.choice([8193, 9000, 16384, 20000, 40000, rng.randint(8193, 40000)])
     L = rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 300, 1000, 2047, 2048, 2049, rng.randint(1, 6000)])
     if S * L > 3_000_000: L = max(1, 3_000_000 // S)
     alph = rng.choice(ALPH)

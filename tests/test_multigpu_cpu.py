@@ -65,6 +65,53 @@ def edges_of(rows, c0, c1, eds, seds):
                         last_eds_bytes=last_e, last_seds_bytes=seds_suffix(k_last))
 
 
+def anchors_of(rows, l, eds, seds):
+    """edsx_msa_anchor_info on the CPU (what MsaSharder's l-EDS path needs from a slab): the first and the last common
+    segment of at least l columns, from the slab's rows (segments by the l-EDS rule, msa_transforms.cpp:133-190) and
+    the slab's oracle output (text offsets: segment i is the i-th brace group of the .eds and owns one source set per
+    string)."""
+    L = len(rows[0])
+    common = [all(r[c] == rows[0][c] for r in rows) and rows[0][c:c + 1] != b"-" for c in range(L)]
+    starts, i, prev_standalone = [], 0, False
+    while i < L:
+        e = i
+        while e < L and common[e] == common[i]:
+            e += 1
+        if common[i]:
+            if (e - i) >= l or i == 0 or e == L:
+                starts.append(i)
+                prev_standalone = True
+            else:
+                if prev_standalone:
+                    starts.append(i)
+                prev_standalone = False
+        elif prev_standalone:
+            starts.append(i)
+            prev_standalone = False
+        i = e
+    if not starts or starts[0] != 0:
+        starts = [0] + starts
+    bounds = starts + [L]
+    eoff, soff, epos, spos = [], [], 0, 0
+    for _ in range(len(starts)):
+        eoff.append(epos)
+        soff.append(spos)
+        close = eds.index(b"}", epos)
+        for _k in range(eds[epos:close].count(b",") + 1):
+            spos = seds.index(b"}", spos) + 1
+        epos = close + 1
+    eoff.append(len(eds))
+    soff.append(len(seds))
+    assert epos == len(eds) and spos == len(seds)
+    anchors = [k for k in range(len(starts)) if common[starts[k]] and bounds[k + 1] - bounds[k] >= l]
+    if not anchors:
+        return {"n_segments": len(starts), "found": 0, "first_seg": 0, "last_seg": 0, "last_col": 0, "last_eds_bytes": 0,
+                "last_seds_bytes": 0, "first_end": 0, "first_eds_end": 0, "first_seds_end": 0}
+    f, t = anchors[0], anchors[-1]
+    return {"n_segments": len(starts), "found": 1, "first_seg": f, "last_seg": t, "last_col": bounds[t], "last_eds_bytes": eoff[t],
+            "last_seds_bytes": soff[t], "first_end": bounds[f + 1], "first_eds_end": eoff[f + 1], "first_seds_end": soff[f + 1]}
+
+
 def stitch_serial(rows, cuts):
     """All ranks simulated in one process with the library's planning functions."""
     S = len(rows)

@@ -36,13 +36,19 @@ def _worker(rank, world, port, tool, argv):
 
 def _oracle_msa_sharder(mg, rank, world, dist):
     """MsaSharder with the oracle in place of the C ABI: slab text from oracle.msa, edges from the slab's rows."""
-    from test_multigpu_cpu import edges_of, rows_of
+    from test_multigpu_cpu import anchors_of, edges_of, rows_of
 
     def slab_fn(image, n_rows, ncols):
         rows = rows_of(image)
         e, s = o.msa(image, 0)
         return e, s, edges_of(rows, 0, ncols, e, s), lambda a, n: b"".join(r[a:a + n] for r in rows)
-    return mg.MsaSharder(rank, world, dist, slab_fn, lambda m: o.msa(m, 0), lambda m, l: o.msa(m, l))
+
+    def leds_fn(image, n_rows, ncols, l):
+        rows = rows_of(image)
+        e, s = o.msa(image, l)
+        return e, s, anchors_of(rows, l, e, s), lambda a, n: b"".join(r[a:a + n] for r in rows)
+    return mg.MsaSharder(rank, world, dist, slab_fn, lambda m: o.msa(m, 0), lambda m, l: o.msa(m, l), leds_fn=leds_fn,
+                         mini_leds_fn=lambda m, l: o.msa(m, l))
 
 
 def _run(tool, argv):
@@ -89,10 +95,12 @@ def test_eds2leds_two_ranks_write_their_pieces(tmp_path, linear):
         assert (tmp_path / "g_l8.seds").read_bytes() == want[1]
 
 
-@pytest.mark.parametrize("seed,lw,l", [(1, None, 0), (2, 7, 0), (3, 60, 0), (4, None, 0), (5, 13, 0), (6, None, 3)])
+@pytest.mark.parametrize("seed,lw,l", [(1, None, 0), (2, 7, 0), (3, 60, 0), (4, None, 0), (5, 13, 0), (6, None, 3), (7, 60, 5),
+                                       (8, None, 2), (9, 7, 40)])
 def test_msa2eds_two_ranks_cut_their_column_slabs(tmp_path, seed, lw, l):
     """File-based msa2eds over two ranks: every rank maps its column slab of every row (wrapped and one-line rows,
-    with and without a trailing newline), stitches, and writes its piece; l > 0 is not partitioned (rank 0 alone)."""
+    with and without a trailing newline), stitches, and writes its piece; l > 0: the boundary is recomputed between the
+    nearest standalone common runs of both slabs, or - no such runs, l = 40 - rank 0 transforms the file."""
     from msa_cases import random_msa
     rng = random.Random(900 + seed)
     S, L = rng.randint(2, 9), rng.randint(30, 400)

@@ -66,6 +66,20 @@ def test_msa2eds_front_end(tmp_path, lw):
     assert "Column slabs: 2" in r.stdout
 
 
+def test_msa2eds_front_end_leds(tmp_path):
+    """The same with a context length: the boundary between the two slabs is recomputed between their nearest common
+    runs of at least l columns (edsx_msa_anchor_info); the pieces equal the oracle's l-EDS."""
+    from msa_cases import random_msa
+    rng = random.Random(80)
+    msa = random_msa(rng, S=40, L=30000, lw=10 ** 6, p_var=0.06)
+    (tmp_path / "a.msa").write_bytes(msa)
+    r = _launch(["msa2eds", "-i", str(tmp_path / "a.msa"), "-l", "6"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = o.msa(msa, 6)
+    assert (tmp_path / "a_l6.leds").read_bytes() == want[0] and (tmp_path / "a_l6.seds").read_bytes() == want[1]
+    assert "Column slabs: 2" in r.stdout
+
+
 def test_rccl_backend_single_rank(tmp_path):
     """The production backend (nccl = RCCL) with the one rank a one-GPU box allows: process-group start-up on the device and
     every tensor collective of the three front ends run through RCCL on device tensors (int64 vectors, uint8 payloads); the
