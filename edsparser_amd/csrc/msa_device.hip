@@ -29,12 +29,14 @@
 // Source layout: this file is the host side (MsaPipeline: sizing, launches, timers) and the one translation unit of the
 // MSA kernels; the device code is in msa_wave.hpp (wave64 helpers, grouping primitives), msa_scan_kernels.hpp (row
 // index, column scan, runs -> segments), msa_generic_kernels.hpp (workgroup per segment, common text) and
-// msa_fast_kernels.hpp (wave per segment: tables, grouping, emitters).
+// msa_fast_kernels.hpp (wave per segment, up to 1024 rows: tables, grouping, emitters) and msa_rowloop_kernels.hpp (wave
+// per segment, any number of rows).
 #include "msa_device.hpp"
 #include "msa_wave.hpp"
 #include "msa_scan_kernels.hpp"
 #include "msa_generic_kernels.hpp"
 #include "msa_fast_kernels.hpp"
+#include "msa_rowloop_kernels.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -424,7 +426,22 @@ void MsaPipeline::plan_body(hipStream_t st)
         sp.list = fp_.slow_list2; sp.list_n = fp_.slow_count2; sp.gcache = gcache_.as<uint8_t>() + gc_region_;
         TIMED("k_seg_count_slow2", st, hipLaunchKernelGGL(k_seg_count<false>, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
     } else {
+        // More than 1024 rows: a wave walks the rows of a variant segment 64 at a time (msa_rowloop_kernels.hpp: up to
+        // eight pure variant columns, up to 64 strings - nearly all segments); what it leaves goes to the generic kernels
+        // as a work list.
+        segmeta_.ensure(8 * (L + 2));
+        slow_list_.ensure(8 * (L / 2 + 4));
+        rl_.mv = mv_; rl_.seg_start = seg_start; rl_.nseg_ptr = d_nseg; rl_.eds_len = eds_len_.as<u64>(); rl_.seds_len = seds_len_.as<u64>();
+        rl_.tok_total = tok_total; rl_.segmeta = segmeta_.as<u64>(); rl_.slow_list = slow_list_.as<u64>(); rl_.slow_count = &dh->slow_n;
+        rl_.long_list = sp.long_list; rl_.long_count = sp.long_count;
+        rl_.rec_stride = rl_stride_of((u32)S);
+        rec_.ensure(((size_t)std::min<u64>(vc_cap_cols_, L / 2 + 2) + 2) * rl_.rec_stride);   // a record per variant segment (<= variant columns)
+        rl_.rec = rec_.as<uint8_t>(); rl_.eds = nullptr; rl_.seds = nullptr;
+        EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, 2 * sizeof(u64), st));
+        TIMED("k_rl_count", st, hipLaunchKernelGGL(k_rl_count, dim3(persistent_grid(reinterpret_cast<const void*>(k_rl_count), 256, 0)),
+                                                   dim3(256), 0, st, rl_));
         sp.gcache_stride = gc_stride_; sp.gcache_cap = 2 * gc_region_ / gc_stride_; sp.gcache = gcache_.as<uint8_t>();
+        sp.list = rl_.slow_list; sp.list_n = rl_.slow_count;
         if (big_) TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count<true>, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
         else TIMED("k_seg_count", st, hipLaunchKernelGGL(k_seg_count<false>, dim3(seg_grid()), dim3(GT), seg_lds_, st, sp));
     }
@@ -644,7 +661,12 @@ void MsaPipeline::emit(uint8_t* d_eds, uint8_t* d_seds, hipStream_t st)
         EDSX_HIP(hipStreamWaitEvent(st, side_ev_[2], 0));
     } else {
         launch_common(st);
+        RlParams rp = rl_;
+        rp.eds = d_eds; rp.seds = d_seds;
+        TIMED("k_rl_emit", st, hipLaunchKernelGGL(k_rl_emit, dim3(persistent_grid(reinterpret_cast<const void*>(k_rl_emit), 256, 0)),
+                                                  dim3(256), 0, st, rp));
         ep.gcache_stride = gc_stride_; ep.gcache_cap = 2 * gc_region_ / gc_stride_; ep.gcache = gcache_.as<uint8_t>();
+        ep.list = rl_.slow_list; ep.list_n = rl_.slow_count;
         if (big_) TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant<true>, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
         else TIMED("k_emit_variant", st, hipLaunchKernelGGL(k_emit_variant<false>, dim3(seg_grid()), dim3(GT), seg_lds_, st, ep));
     }

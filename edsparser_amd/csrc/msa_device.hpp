@@ -148,6 +148,16 @@ struct FastParams {
     u64* long_list; u64* long_count;        // common segments for k_emit_common_long
 };
 
+// parameters of the row-loop kernels (more than 1024 rows), see msa_rowloop_kernels.hpp
+struct RlParams {
+    MsaView mv; const u64* seg_start; const u64* nseg_ptr; u64* eds_len; u64* seds_len; u64 tok_total;
+    u64* segmeta;                             // per segment: META_REC | vi when the row-loop kernels own it, else 0
+    u64* slow_list; u64* slow_count;          // variant segments for the generic kernels
+    u64* long_list; u64* long_count;          // common segments for k_emit_common_long
+    uint8_t* rec; u64 rec_stride;
+    uint8_t* eds; uint8_t* seds;              // emit pass (eds_len / seds_len hold the offsets then)
+};
+
 class MsaPipeline {
 public:
     static constexpr u64 MAX_ROWS = 9999999;   // sequence ids of up to seven digits (an id + ',' is one 8-byte token)
@@ -205,6 +215,7 @@ private:
     u32 stage_off_ = 0, stage_cols_ = 0;   // generic kernels: column staging area in their LDS (offset, capacity; 0: none)
     bool fast_ = false, fuse_ = false;
     u32 recf_stride_ = 0, recf_gid_ = 0;
+    RlParams rl_{};                          // more than 1024 rows: the row-loop kernels' parameters (plan -> emit)
     bool big_ = false;                       // more than LDS_ROWS rows
     unsigned big_grid_ = 0;
     DevBuf seg_scratch_; size_t seg_scratch_stride_ = 0;      // ... their row tables: one slice per workgroup

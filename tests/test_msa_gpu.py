@@ -500,3 +500,42 @@ def test_alignment_that_does_not_fit_in_one_piece_is_batched(ctx):
         c2.close()
     assert got == want
     assert batches >= 2
+
+
+def test_row_loop_kernels_and_their_fallbacks(ctx):
+    """More than 1024 rows: a wave walks the rows of a variant segment 64 at a time (msa_rowloop_kernels.hpp) when it has
+    at most eight pure variant columns and at most 64 strings; a wider run, a segment with more strings, a NUL byte and
+    (l > 0) mixed segments go to the generic kernels.  Constructed alignment: 40 narrow sites, one run of 12 columns, one
+    site with 100 different letters/strings, one site with a NUL - the routing is checked through n_slow_segments."""
+    import numpy as np
+    rng = np.random.default_rng(17)
+    for S in (1025, 1500, 4100, 9000):
+        L = 600
+        ref = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=L)]
+        rows = np.tile(ref, (S, 1))
+        sites = list(range(10, 410, 10))                                     # 40 narrow sites (1..3 columns, gaps, few strings)
+        for c in sites:
+            w = int(rng.integers(1, 4))
+            for j in range(w):
+                alt = np.frombuffer(b"ACGT-", dtype=np.uint8)[rng.integers(0, 5, size=S)]
+                pick = rng.random(S) < 0.4
+                pick[0] = False
+                rows[pick, c + j] = alt[pick]
+        wide = slice(450, 462)                                                # a run of 12 variant columns
+        rows[1::2, wide] = np.frombuffer(b"TTTTTTTTTTTT", dtype=np.uint8)
+        rows[0, wide] = np.frombuffer(b"GGGGGGGGGGGG", dtype=np.uint8)
+        rows[2, wide] = np.frombuffer(b"GGGGGGGGGGGG", dtype=np.uint8)
+        many = 500                                                            # two columns, 100 distinct strings
+        rows[0, many:many + 2] = np.frombuffer(b"AA", dtype=np.uint8)
+        for r in range(1, S):
+            v = r % 100
+            rows[r, many] = 65 + v // 10
+            rows[r, many + 1] = 97 + v % 10
+        rows[5, 550] = 0                                                      # a NUL byte (ends the row's string)
+        rows[6, 550] = ord("T") if ref[550] != ord("T") else ord("A")
+        msa = b"".join(b">s%d\n" % i + rows[i].tobytes() + b"\n" for i in range(S))
+        assert _same_as_oracle(ctx, msa, 0), S
+        slow = ctx.msa_info()["n_slow_segments"]
+        assert slow == 3, (S, slow)                                           # the wide run, the 100-string site, the NUL site
+        assert _same_as_oracle(ctx, msa, 4), S                                # l-EDS: mixed segments take the generic kernels
+        assert ctx.msa_info()["n_slow_segments"] >= 3
