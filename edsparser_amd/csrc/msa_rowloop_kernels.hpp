@@ -3,21 +3,21 @@
 //
 // The wave-per-segment kernels of msa_fast_kernels.hpp keep a segment's rows in registers (16 per lane, at most 1024).
 // Here a wave WALKS the rows of its segment 64 at a time, one row per lane: a variant segment of up to RL_MAXCOLS pure
-// variant columns has strings of at most eight letters, so a row's gap-stripped string IS a 64-bit key (first letter in
-// byte 0: exact, msa_transforms.cpp:262-293), the distinct strings live one per lane (at most 64, in the order of their
-// first rows), and a row block is matched against them with one ballot per string.  That covers nearly every variant
-// segment of an EDS (runs of 1..8 columns); wider or mixed segments (l-EDS), more than 64 strings and rows with a NUL
+// variant columns has strings of at most sixteen letters, so a row's gap-stripped string IS a 128-bit key (first letter
+// in byte 0: exact, msa_transforms.cpp:262-293), the distinct strings live one per lane (at most 64, in the order of
+// their first rows), and a row block is matched against them with one ballot per string.  That covers nearly every
+// variant segment of an EDS (runs of 1..16 columns); wider or mixed segments (l-EDS), more than 64 strings and rows with a NUL
 // byte go on the work list of the generic workgroup-per-segment kernels (msa_generic_kernels.hpp), which were the only
 // path for more than 1024 rows until round 3 (2000 rows x 2 M columns: 490 GB/s).
-//   record of variant segment vi (rl_rec + vi * stride):  u32 k | per string g < 64: u64 key at 16 + 8 g, u32 .seds
-//   bytes of its id list at 528 + 4 g | group id of every row (u8) from RL_GID on
+//   record of variant segment vi (rl_rec + vi * stride):  u32 k | per string g < 64: its key (2 x u64) at 16 + 16 g, the
+//   .seds bytes of its id list (u32) at 1040 + 4 g | group id of every row (u8) from RL_GID on
 #pragma once
 #include "msa_fast_kernels.hpp"
 
 namespace edsx {
 
-constexpr u32 RL_MAXCOLS = 8, RL_KMAX = 64;
-constexpr u32 RL_KEYS = 16, RL_TOT = RL_KEYS + 8 * RL_KMAX, RL_GID = 800;
+constexpr u32 RL_MAXCOLS = 16, RL_KMAX = 64, RL_UNROLL = 2;
+constexpr u32 RL_KEYS = 16, RL_TOT = RL_KEYS + 16 * RL_KMAX, RL_GID = 1344;
 __host__ __device__ inline u64 rl_stride_of(u32 S) { return ((u64)RL_GID + S + 63u) & ~(u64)63u; }
 
 __device__ __forceinline__ u64 readlane64(u64 v, int lane)
@@ -26,6 +26,17 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane)
 }
 // letters of an exact key (non-zero bytes from byte 0 up)
 __device__ __forceinline__ u32 rl_key_len(u64 key) { return key ? (71u - (u32)__builtin_clzll(key)) / 8u : 0u; }
+
+// "<id>," lengths of the 64 rows r0 .. r0+63 (ids r0+1 ..): at most two lengths, tlA for the lanes of maskA and tlA + 1
+// for the others; the first id of the block decides on the scalar unit, one compare per lane
+__device__ __forceinline__ void rl_token_lengths(u32 r0, u32 lane, bool valid, u32& tlA, u64& maskA)
+{
+    const u32 first = r0 + 1;                              // (uniform)
+    u32 p10 = 10, d = 1;
+    while (first >= p10 && d < 9) { p10 *= 10; d++; }     // p10 = the first id with one digit more
+    tlA = d + 1;
+    maskA = ballot64(valid && r0 + lane + 1 < p10);
+}
 
 // sizes: common segments (a thread each), then a wave per variant segment
 __global__ void __launch_bounds__(256) k_rl_count(RlParams p)
@@ -50,67 +61,80 @@ __global__ void __launch_bounds__(256) k_rl_count(RlParams p)
         const u64 a = uniform64(p.seg_start[seg]), b = uniform64(p.seg_start[seg + 1]);
         const u32 ncol = (u32)(b - a);
         bool mine = ncol <= RL_MAXCOLS;
-        u64 base[RL_MAXCOLS];                              // (uniform) first byte of every column in vc
+        u64 colbase = 0;                                   // lane c: first byte of column c in vc
         if (mine) {
-            u64 sl = 0;
             bool var = true;
-            if (lane < ncol) { var = mv.vbit(a + lane); sl = mv.slot(a + lane); }
+            if (lane < ncol) { var = mv.vbit(a + lane); colbase = mv.slot(a + lane) * (u64)mv.Spad; }
             mine = !ballot64(!var);                        // an l-EDS segment with common columns inside: generic
-#pragma unroll
-            for (int c = 0; c < (int)RL_MAXCOLS; c++) base[c] = readlane64(sl, c) * (u64)mv.Spad;
         }
-        u64 K = 0;                                         // lane g: the key of string g
+        const bool wide = ncol > 8u;                       // (uniform) strings of more than eight letters are possible
+        u64 K = 0, K2 = 0;                                 // lane g: the key of string g (letters 0..7, 8..15)
         u32 TOT = 0, k = 0;                                // ... the bytes of its id list; strings so far (uniform)
         uint8_t* rec = p.rec + vi * p.rec_stride;
-        for (u32 r0 = 0; r0 < S && mine; r0 += 64) {
-            const u32 r = r0 + lane;
-            const bool valid = r < S;
-            u64 key = 0;
-            u32 len = 0, nul = 0;
+        // RL_UNROLL blocks of 64 rows per step: the column bytes of all of them are requested before the first block is
+        // matched (four blocks per step measured no faster than one: the kernel is bound by its instructions)
+        for (u32 r0 = 0; r0 < S && mine; r0 += 64 * RL_UNROLL) {
+            u64 key[RL_UNROLL], key2[RL_UNROLL];
+            u32 nul = 0;
 #pragma unroll
-            for (int c = 0; c < (int)RL_MAXCOLS; c++) {
-                if (c < (int)ncol) {
-                    const u32 ch = valid ? (u32)mv.vc[base[c] + r] : (u32)'-';
+            for (int u = 0; u < (int)RL_UNROLL; u++) {
+                const u32 r = r0 + 64u * (u32)u + lane;
+                const bool valid = r < S;
+                u32 len = 0;
+                key[u] = 0; key2[u] = 0;
+                // (a loop of exactly ncol steps with the column's base read from lane c: sixteen unrolled steps behind a
+                // scalar branch each cost more than the one or two columns most segments have - 2.0 vs 1.3 ms)
+                for (u32 c = 0; c < ncol; c++) {
+                    const u64 cb = readlane64(colbase, (int)c);
+                    const u32 ch = valid ? (u32)mv.vc[cb + r] : (u32)'-';
                     nul |= ch == 0 ? 1u : 0u;
                     const bool keep = ch != '-' && ch != '\n';
-                    key |= keep ? (u64)ch << (8u * len) : 0ull;
+                    const u64 put = keep ? (u64)ch << (8u * (len & 7u)) : 0ull;
+                    if (!wide || len < 8u) key[u] |= put; else key2[u] |= put;
                     len += keep ? 1u : 0u;
                 }
             }
             if (ballot64(nul != 0)) { mine = false; break; }           // '\0' ends a row's string (msa_transforms.cpp:282): generic
-            const u32 tl = ndigits(r + 1) + 1;                           // "<id>,"
-            const u32 tlA = (u32)__builtin_amdgcn_readfirstlane((int)tl);   // at most two token lengths in 64 consecutive ids
-            const u64 maskA = ballot64(valid && tl == tlA);
-            u32 gid = 0;
-            u64 todo = ballot64(valid);
-            for (u32 g = 0; g < k && todo; g++) {                       // the strings known so far
-                const u64 kg = readlane64(K, (int)g);
-                const u64 m = ballot64(valid && key == kg) & todo;
-                if ((m >> lane) & 1ull) gid = g;
-                if (lane == g) TOT += (u32)__builtin_popcountll(m & maskA) * tlA + (u32)__builtin_popcountll(m & ~maskA) * (tlA + 1u);
-                todo &= ~m;
+#pragma unroll
+            for (int u = 0; u < (int)RL_UNROLL; u++) {
+                const u32 r = r0 + 64u * (u32)u + lane;
+                const bool valid = r < S;
+                if (r0 + 64u * (u32)u >= S || !mine) break;             // (uniform)
+                u32 tlA;
+                u64 maskA;
+                rl_token_lengths(r0 + 64u * (u32)u, lane, valid, tlA, maskA);
+                u32 gid = 0;
+                u64 todo = ballot64(valid);
+                for (u32 g = 0; g < k && todo; g++) {                       // the strings known so far
+                    const u64 kg = readlane64(K, (int)g), kg2 = wide ? readlane64(K2, (int)g) : 0ull;
+                    const u64 m = ballot64(valid && key[u] == kg && (!wide || key2[u] == kg2)) & todo;
+                    if ((m >> lane) & 1ull) gid = g;
+                    if (lane == g) TOT += (u32)__builtin_popcountll(m & maskA) * tlA + (u32)__builtin_popcountll(m & ~maskA) * (tlA + 1u);
+                    todo &= ~m;
+                }
+                while (todo) {                                              // new strings, in the order of their first rows
+                    if (k == RL_KMAX) { mine = false; break; }
+                    const int leader = __builtin_ctzll(todo);
+                    const u64 nk = readlane64(key[u], leader), nk2 = wide ? readlane64(key2[u], leader) : 0ull;
+                    const u64 m = ballot64(valid && key[u] == nk && (!wide || key2[u] == nk2)) & todo;
+                    if ((m >> lane) & 1ull) gid = k;
+                    if (lane == k) { K = nk; K2 = nk2; TOT = (u32)__builtin_popcountll(m & maskA) * tlA + (u32)__builtin_popcountll(m & ~maskA) * (tlA + 1u); }
+                    k++;
+                    todo &= ~m;
+                }
+                if (!mine) break;
+                if (valid) rec[RL_GID + r] = (uint8_t)gid;
             }
-            while (todo) {                                              // new strings, in the order of their first rows
-                if (k == RL_KMAX) { mine = false; break; }
-                const int leader = __builtin_ctzll(todo);
-                const u64 nk = readlane64(key, leader);
-                const u64 m = ballot64(valid && key == nk) & todo;
-                if ((m >> lane) & 1ull) gid = k;
-                if (lane == k) { K = nk; TOT = (u32)__builtin_popcountll(m & maskA) * tlA + (u32)__builtin_popcountll(m & ~maskA) * (tlA + 1u); }
-                k++;
-                todo &= ~m;
-            }
-            if (!mine) break;
-            if (valid) rec[RL_GID + r] = (uint8_t)gid;
         }
         if (!mine) {
             if (lane == 0) { p.slow_list[atomicAdd(p.slow_count, 1ull)] = seg; p.segmeta[seg] = 0; }
             continue;
         }
-        u32 sum = lane < k ? rl_key_len(K) : 0u;
+        u32 sum = lane < k ? rl_key_len(K) + rl_key_len(K2) : 0u;
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         if (lane < k) {
-            *reinterpret_cast<u64*>(rec + RL_KEYS + 8u * lane) = K;
+            *reinterpret_cast<u64*>(rec + RL_KEYS + 16u * lane) = K;
+            *reinterpret_cast<u64*>(rec + RL_KEYS + 16u * lane + 8u) = K2;
             *reinterpret_cast<u32*>(rec + RL_TOT + 4u * lane) = TOT;
         }
         if (lane == 0) {
@@ -137,20 +161,24 @@ __global__ void __launch_bounds__(256) k_rl_emit(RlParams p)
         if (!(uniform64(p.segmeta[seg]) & META_REC)) continue;          // a segment of the generic kernels
         const uint8_t* rec = p.rec + vi * p.rec_stride;
         const u32 k = uniform32(*reinterpret_cast<const u32*>(rec));
-        u64 K = 0;
+        u64 K = 0, K2 = 0;
         u32 TOT = 0;
-        if (lane < k) { K = *reinterpret_cast<const u64*>(rec + RL_KEYS + 8u * lane); TOT = *reinterpret_cast<const u32*>(rec + RL_TOT + 4u * lane); }
+        if (lane < k) {
+            K = *reinterpret_cast<const u64*>(rec + RL_KEYS + 16u * lane); K2 = *reinterpret_cast<const u64*>(rec + RL_KEYS + 16u * lane + 8u);
+            TOT = *reinterpret_cast<const u32*>(rec + RL_TOT + 4u * lane);
+        }
         uint8_t* eds = p.eds + uniform64(p.eds_len[seg]);
         uint8_t* seds = p.seds + uniform64(p.seds_len[seg]);
         // ---- .eds: "{" s0 "," s1 ... "}"
         {
-            const u32 len = rl_key_len(K), mine = lane < k ? len + 1u : 0u;
+            const u32 len1 = rl_key_len(K), len = len1 + rl_key_len(K2), mine = lane < k ? len + 1u : 0u;
             u32 incl = mine;
             for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += x; }
             const u32 at = 1u + incl - mine;
             if (lane == 0) eds[0] = '{';
             if (lane < k) {
-                for (u32 i = 0; i < len; i++) eds[at + i] = (uint8_t)(K >> (8u * i));
+                for (u32 i = 0; i < len; i++) eds[at + i] = (uint8_t)((i < 8u ? K : K2) >> (8u * (i & 7u)));
+                (void)len1;
                 eds[at + len] = lane + 1u < k ? ',' : '}';
             }
         }
@@ -164,29 +192,49 @@ __global__ void __launch_bounds__(256) k_rl_emit(RlParams p)
             if (lane < k) seds[cursor] = '{';
             cursor += 1u;
         }
-        for (u32 r0 = 0; r0 < S; r0 += 64) {
-            const u32 r = r0 + lane;
-            const bool valid = r < S;
-            const u32 gid = valid ? (u32)rec[RL_GID + r] : 0xffffu;
-            const u32 tl = ndigits(r + 1) + 1;
-            const u32 tlA = (u32)__builtin_amdgcn_readfirstlane((int)tl);
-            const u64 maskA = ballot64(valid && tl == tlA);
-            u32 myoff = 0;
-            u64 todo = ballot64(valid);
-            while (todo) {                                              // one step per distinct string of the block
-                const int leader = __builtin_ctzll(todo);
-                const u32 g0 = (u32)__builtin_amdgcn_readlane((int)gid, leader);
-                const u64 m = ballot64(valid && gid == g0);
-                const u32 start = (u32)__builtin_amdgcn_readlane((int)cursor, (int)g0);
-                if ((m >> lane) & 1ull) myoff = start + mbcnt(m & maskA) * tlA + mbcnt(m & ~maskA) * (tlA + 1u);
-                if (lane == g0) cursor = start + (u32)__builtin_popcountll(m & maskA) * tlA + (u32)__builtin_popcountll(m & ~maskA) * (tlA + 1u);
-                todo &= ~m;
+        for (u32 r0 = 0; r0 < S; r0 += 64 * RL_UNROLL) {
+            u32 gidv[RL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < (int)RL_UNROLL; u++) {                   // the group ids of RL_UNROLL blocks in one round trip
+                const u32 r = r0 + 64u * (u32)u + lane;
+                gidv[u] = r < S ? (u32)rec[RL_GID + r] : 0xffffu;
             }
-            if (valid) {                                                // "<id>," digit by digit (ids of up to seven digits)
-                uint8_t* dst = seds + myoff;
-                u32 v = r + 1;
-                dst[tl - 1] = ',';
-                for (int i = (int)tl - 2; i >= 0; i--) { dst[i] = (uint8_t)('0' + v % 10u); v /= 10u; }
+#pragma unroll
+            for (int u = 0; u < (int)RL_UNROLL; u++) {
+                const u32 r = r0 + 64u * (u32)u + lane;
+                const bool valid = r < S;
+                if (r0 + 64u * (u32)u >= S) break;                         // (uniform)
+                const u32 gid = gidv[u];
+                u32 tlA;
+                u64 maskA;
+                rl_token_lengths(r0 + 64u * (u32)u, lane, valid, tlA, maskA);
+                const u32 tl = ((maskA >> lane) & 1ull) ? tlA : tlA + 1u;
+                u32 myoff = 0;
+                u64 todo = ballot64(valid);
+                while (todo) {                                              // one step per distinct string of the block
+                    const int leader = __builtin_ctzll(todo);
+                    const u32 g0 = (u32)__builtin_amdgcn_readlane((int)gid, leader);
+                    const u64 m = ballot64(valid && gid == g0);
+                    const u32 start = (u32)__builtin_amdgcn_readlane((int)cursor, (int)g0);
+                    if ((m >> lane) & 1ull) myoff = start + mbcnt(m & maskA) * tlA + mbcnt(m & ~maskA) * (tlA + 1u);
+                    if (lane == g0) cursor = start + (u32)__builtin_popcountll(m & maskA) * tlA + (u32)__builtin_popcountll(m & ~maskA) * (tlA + 1u);
+                    todo &= ~m;
+                }
+                if (valid) {                                                // "<id>," (ids of up to seven digits): built in a register,
+                    u64 tok = (u64)',' << (8u * (tl - 1u));                 // stored as 4 + 1 / 2 / 4 bytes or 2 + 1
+                    u32 v = r + 1;
+                    for (int i = (int)tl - 2; i >= 0; i--) { tok |= (u64)('0' + v % 10u) << (8 * i); v /= 10u; }
+                    uint8_t* dst = seds + myoff;
+                    if (tl >= 4u) {
+                        store_small<4>(dst, tok);
+                        if (tl == 5u) dst[4] = (uint8_t)(tok >> 32);
+                        else if (tl == 6u) store_small<2>(dst + 4, tok >> 32);
+                        else if (tl >= 7u) store_small<4>(dst + tl - 4u, tok >> (8u * (tl - 4u)));
+                    } else {
+                        store_small<2>(dst, tok);
+                        if (tl == 3u) dst[2] = (uint8_t)(tok >> 16);
+                    }
+                }
             }
         }
         // every id has landed before the closing braces overwrite the last ',' of their lists

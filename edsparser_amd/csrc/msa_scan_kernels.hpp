@@ -641,17 +641,31 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                 }
             }
             if (nv && !overflow && V16) {
-                u32 m = V16, idx = pre_of(j);
-                while (m) {
-                    const int i = __builtin_ctz(m);
-                    m &= m - 1;
-                    uint8_t* dst = p.vc + (slot_base + idx) * (u64)p.Spad;
-                    for (u32 r = sub; r < p.S; r += RI) {
-                        const u32 ch = f[p.row_start[r] + q + i];
-                        if (ch == '\n') bad = 1;
-                        dst[r] = (uint8_t)ch;
+                uint8_t* const dst0 = p.vc + (slot_base + pre_of(j)) * (u64)p.Spad;
+                for (u32 r = sub; r < p.S; r += 4 * RI) {          // rows outside, four in flight (see the batched path below)
+                    uint4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const u32 rr = r + (u32)u * RI;
+                        v[u] = make_uint4(0, 0, 0, 0);
+                        if (rr < p.S) v[u] = nb == 16 ? load16u(f + p.row_start[rr] + q) : load_partial(f + p.row_start[rr] + q, nb);
                     }
-                    idx++;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const u32 rr = r + (u32)u * RI;
+                        if (rr < p.S) {
+                            u32 m = V16;
+                            uint8_t* dst = dst0 + rr;
+                            while (m) {
+                                const int i = __builtin_ctz(m);
+                                m &= m - 1;
+                                const u32 ch = byte_of(v[u], i);
+                                if (ch == '\n') bad = 1;
+                                *dst = (uint8_t)ch;
+                                dst += p.Spad;
+                            }
+                        }
+                    }
                 }
             }
         } else
@@ -687,19 +701,34 @@ __global__ void __launch_bounds__(T, MINW) k_scan_extract(K1Params p)
                     EDSX_X(8) EDSX_X(9) EDSX_X(10) EDSX_X(11) EDSX_X(12) EDSX_X(13) EDSX_X(14) EDSX_X(15)
 #undef EDSX_X
                 } else {
-                    u32 m = V16;
-                    while (m) {
-                        const int i = __builtin_ctz(m);
-                        m &= m - 1;
-                        if (idx >= b0 && idx < b0 + cap) {
-                            uint8_t* dst = colbuf + (size_t)(idx - b0) * p.Spad;
-                            for (u32 r = sub; r < p.S; r += RI) {
-                                u32 ch = f[p.row_start[r] + q + i];
-                                if (ch == '\n') bad = 1;
-                                dst[r] = (uint8_t)ch;
+                    // rows outside: a row's 16-byte chunk is fetched once more (it is in L2 from the first pass) and its
+                    // variant bytes are picked out of the registers, four rows in flight - not a byte load per variant
+                    // column and row behind a row-start load each (3000 rows x 1 M columns: scan 4.6 -> see DESIGN)
+                    for (u32 r = sub; r < p.S; r += 4 * RI) {
+                        uint4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const u32 rr = r + (u32)u * RI;
+                            v[u] = make_uint4(0, 0, 0, 0);
+                            if (rr < p.S) v[u] = nb == 16 ? load16u(f + p.row_start[rr] + q) : load_partial(f + p.row_start[rr] + q, nb);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const u32 rr = r + (u32)u * RI;
+                            if (rr < p.S) {
+                                u32 m = V16, id = idx;
+                                while (m) {
+                                    const int i = __builtin_ctz(m);
+                                    m &= m - 1;
+                                    if (id >= b0 && id < b0 + cap) {
+                                        const u32 ch = byte_of(v[u], i);
+                                        if (ch == '\n') bad = 1;
+                                        colbuf[(size_t)(id - b0) * p.Spad + rr] = (uint8_t)ch;
+                                    }
+                                    id++;
+                                }
                             }
                         }
-                        idx++;
                     }
                 }
             }

@@ -504,8 +504,8 @@ def test_alignment_that_does_not_fit_in_one_piece_is_batched(ctx):
 
 def test_row_loop_kernels_and_their_fallbacks(ctx):
     """More than 1024 rows: a wave walks the rows of a variant segment 64 at a time (msa_rowloop_kernels.hpp) when it has
-    at most eight pure variant columns and at most 64 strings; a wider run, a segment with more strings, a NUL byte and
-    (l > 0) mixed segments go to the generic kernels.  Constructed alignment: 40 narrow sites, one run of 12 columns, one
+    at most sixteen pure variant columns and at most 64 strings; a wider run, a segment with more strings, a NUL byte and
+    (l > 0) mixed segments go to the generic kernels.  Constructed alignment: 40 narrow sites, runs of 12 and of 20 columns, one
     site with 100 different letters/strings, one site with a NUL - the routing is checked through n_slow_segments."""
     import numpy as np
     rng = np.random.default_rng(17)
@@ -513,18 +513,20 @@ def test_row_loop_kernels_and_their_fallbacks(ctx):
         L = 600
         ref = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=L)]
         rows = np.tile(ref, (S, 1))
-        sites = list(range(10, 410, 10))                                     # 40 narrow sites (1..3 columns, gaps, few strings)
+        sites = list(range(10, 410, 10))                                     # 40 narrow sites (1..2 columns with gaps: at most 25 strings)
         for c in sites:
-            w = int(rng.integers(1, 4))
+            w = int(rng.integers(1, 3))
             for j in range(w):
                 alt = np.frombuffer(b"ACGT-", dtype=np.uint8)[rng.integers(0, 5, size=S)]
                 pick = rng.random(S) < 0.4
                 pick[0] = False
                 rows[pick, c + j] = alt[pick]
-        wide = slice(450, 462)                                                # a run of 12 variant columns
-        rows[1::2, wide] = np.frombuffer(b"TTTTTTTTTTTT", dtype=np.uint8)
-        rows[0, wide] = np.frombuffer(b"GGGGGGGGGGGG", dtype=np.uint8)
-        rows[2, wide] = np.frombuffer(b"GGGGGGGGGGGG", dtype=np.uint8)
+        wide = slice(450, 470)                                                # a run of 20 variant columns
+        rows[1::2, wide] = np.frombuffer(b"T" * 20, dtype=np.uint8)
+        rows[0, wide] = np.frombuffer(b"G" * 20, dtype=np.uint8)
+        rows[2, wide] = np.frombuffer(b"G" * 20, dtype=np.uint8)
+        rows[3, 430:442] = np.frombuffer(b"CCCC--AAAAAA", dtype=np.uint8)      # a run of 12 columns: still the row-loop kernels
+        rows[4, 430:442] = np.frombuffer(b"AAAAAATTTTTT", dtype=np.uint8)
         many = 500                                                            # two columns, 100 distinct strings
         rows[0, many:many + 2] = np.frombuffer(b"AA", dtype=np.uint8)
         for r in range(1, S):
