@@ -171,14 +171,13 @@ __global__ void __launch_bounds__(256) k_rl_emit(RlParams p)
         uint8_t* seds = p.seds + uniform64(p.seds_len[seg]);
         // ---- .eds: "{" s0 "," s1 ... "}"
         {
-            const u32 len1 = rl_key_len(K), len = len1 + rl_key_len(K2), mine = lane < k ? len + 1u : 0u;
+            const u32 len = rl_key_len(K) + rl_key_len(K2), mine = lane < k ? len + 1u : 0u;
             u32 incl = mine;
             for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += x; }
             const u32 at = 1u + incl - mine;
             if (lane == 0) eds[0] = '{';
             if (lane < k) {
                 for (u32 i = 0; i < len; i++) eds[at + i] = (uint8_t)((i < 8u ? K : K2) >> (8u * (i & 7u)));
-                (void)len1;
                 eds[at + len] = lane + 1u < k ? ',' : '}';
             }
         }

@@ -541,3 +541,29 @@ def test_row_loop_kernels_and_their_fallbacks(ctx):
         assert slow == 3, (S, slow)                                           # the wide run, the 100-string site, the NUL site
         assert _same_as_oracle(ctx, msa, 4), S                                # l-EDS: mixed segments take the generic kernels
         assert ctx.msa_info()["n_slow_segments"] >= 3
+
+
+def test_row_chain_with_headers_of_every_length(ctx):
+    """The row index when headers vary in length (the speculative parallel index does not apply): the chain requests the
+    windows of the next eight rows on the prediction that their headers are as long as the last one.  Header lengths that
+    drift slowly, jump, alternate, exceed the 64-byte window, and the `>s<idx>` style whose length grows with the digits;
+    2 .. 5000 rows; with and without a final newline."""
+    rng = random.Random(64)
+    styles = [lambda i: "s%d" % i, lambda i: "seq", lambda i: "x" * (1 + i % 3), lambda i: "n" * rng.randint(0, 40),
+              lambda i: "L" * (rng.choice([3, 3, 3, 70, 130])), lambda i: "d" * (5 + i // 50), lambda i: "a" if i % 2 else "b" * 33]
+    for S in (2, 9, 65, 700, 5000):
+        for st in styles:
+            L = rng.choice([1, 7, 40, 300])
+            ref = "".join(rng.choice("ACGT") for _ in range(L))
+            rows = []
+            for i in range(S):
+                r = list(ref)
+                if i and rng.random() < 0.3:
+                    r[rng.randrange(L)] = rng.choice("ACGT-")
+                rows.append("".join(r))
+            text = "".join(">%s\n%s\n" % (st(i), rows[i]) for i in range(S))
+            if rng.random() < 0.3:
+                text = text[:-1]
+            msa = text.encode()
+            for l in (0, 2):
+                assert ctx.msa_transform(msa, l) == o.msa(msa, l), (S, L, l)
