@@ -20,7 +20,6 @@
 //                   bit matrix.
 #include "vcf_device.hpp"
 
-#include <hipcub/hipcub.hpp>     // DeviceRadixSort for unsorted VCFs with distinct positions (a commodity sort)
 
 #include <algorithm>
 #include <cstring>
@@ -609,9 +608,61 @@ __global__ void k_vt_ascending(const u64* __restrict__ pos, u64 nrec, VtCtl* ctl
     for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j + 1 < nrec; j += (u64)gridDim.x * blockDim.x) un |= pos[j] >= pos[j + 1];
     if (un) ctl->t_alt = 1;                                      // scratch until the offset scans overwrite it
 }
-__global__ void k_vt_iota(u32* __restrict__ v, u64 n)
+// ---- LSD radix sort of (u64 key, u32 value) pairs: eight stable passes of eight bits (unsorted VCFs with distinct
+// positions only; the usual VCF ascends and skips it).  A wave owns a tile of RS_TILE consecutive elements: pass 1 counts
+// its digits into a bin-major table (bin * ntiles + tile), one exclusive scan over the table gives every (bin, tile) its
+// first output position, pass 2 walks the tile 64 elements at a time - lanes with the same digit find each other with
+// one ballot per digit bit, their rank among them keeps the order stable - and moves the running positions in LDS.
+constexpr u32 RS_TILE = 2048;
+__global__ void __launch_bounds__(64) k_rs_hist(const u64* __restrict__ keys, u64 n, u32 shift, u64 ntiles, u64* __restrict__ table)
 {
-    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < n; j += (u64)gridDim.x * blockDim.x) v[j] = (u32)j;
+    __shared__ u32 hist[256];
+    const u32 lane = threadIdx.x;
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (u32 b = lane; b < 256; b += 64) hist[b] = 0;
+        __syncthreads();
+        const u64 base = tile * RS_TILE;
+        for (u32 o = lane; o < RS_TILE; o += 64)
+            if (base + o < n) atomicAdd(&hist[(u32)(keys[base + o] >> shift) & 0xffu], 1u);
+        __syncthreads();
+        for (u32 b = lane; b < 256; b += 64) table[(u64)b * ntiles + tile] = hist[b];
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(64) k_rs_scatter(const u64* __restrict__ keys, const u32* __restrict__ vals, u64 n, u32 shift,
+                                                   u64 ntiles, const u64* __restrict__ table, u64* __restrict__ keys_out,
+                                                   u32* __restrict__ vals_out)
+{
+    __shared__ u64 at[256];                                    // next output position of every digit of this tile
+    const u32 lane = threadIdx.x;
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (u32 b = lane; b < 256; b += 64) at[b] = table[(u64)b * ntiles + tile];
+        __syncthreads();
+        const u64 base = tile * RS_TILE;
+        for (u32 o = 0; o < RS_TILE && base + o < n; o += 64) {
+            const u64 i = base + o + lane;
+            const bool valid = i < n;
+            const u64 key = valid ? keys[i] : 0;
+            const u32 val = valid ? (vals ? vals[i] : (u32)i) : 0u;         // vals == nullptr: the element's index (first pass)
+            const u32 d = (u32)(key >> shift) & 0xffu;
+            u64 same = ballot64(valid);                                      // lanes with this lane's digit
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const u64 m = ballot64(valid && ((d >> b) & 1u));
+                same &= ((d >> b) & 1u) ? m : ~m;
+            }
+            const u32 rank = mbcnt(same);
+            if (valid) {
+                const u64 pos = at[d] + rank;
+                keys_out[pos] = key;
+                vals_out[pos] = val;
+            }
+            __syncthreads();                                                 // (one wave: every lane has read at[] before it moves)
+            if (valid && rank == 0) at[d] += (u64)__builtin_popcountll(same);
+            __syncthreads();
+        }
+        __syncthreads();
+    }
 }
 // counts in sorted order (inputs of the four offset scans)
 __global__ void k_vt_gather(VtRec r, const u32* __restrict__ order, u64 nrec, u64* __restrict__ a, u64* __restrict__ b,
@@ -909,14 +960,26 @@ bool VcfPipeline::tokenize_device(const uint8_t* vcf, size_t n, bool presorted, 
         // Not ascending.  If the positions are pairwise distinct there is exactly one sorted order, so a device radix
         // sort gives the reference's permutation; equal positions (checked on the sorted keys) need the host's
         // std::sort, whose unstable permutation of them is part of the output.
-        vt_s2_.ensure(8 * (nr + 2)); vt_s3_.ensure(4 * (nr + 2)); vt_order_.ensure(4 * (nr + 1));
-        hipLaunchKernelGGL(k_vt_iota, dim3(1024), dim3(256), 0, st, vt_s3_.as<u32>(), nr);
-        size_t tmp_bytes = 0;
-        EDSX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, vt_pos_.as<u64>(), vt_s2_.as<u64>(), vt_s3_.as<u32>(),
-                                                    vt_order_.as<u32>(), (int)nr, 0, 64, st));
-        vt_sorttmp_.ensure(tmp_bytes + 16);
-        EDSX_HIP(hipcub::DeviceRadixSort::SortPairs(vt_sorttmp_.ptr, tmp_bytes, vt_pos_.as<u64>(), vt_s2_.as<u64>(), vt_s3_.as<u32>(),
-                                                    vt_order_.as<u32>(), (int)nr, 0, 64, st));
+        vt_s2_.ensure(8 * (nr + 2)); vt_order_.ensure(4 * (nr + 1));
+        {   // eight passes: positions -> tmp -> (vt_s2_, vt_order_) -> tmp ... the last pass ends in (vt_s2_, vt_order_)
+            const u64 ntiles = (nr + RS_TILE - 1) / RS_TILE, nbins = 256 * ntiles;
+            vt_sorttmp_.ensure(12 * (nr + 2) + 8 * (nbins + 2) + 64);
+            u64* tkeys = vt_sorttmp_.as<u64>();
+            u32* tvals = reinterpret_cast<u32*>(tkeys + nr + 2);
+            u64* table = reinterpret_cast<u64*>(vt_sorttmp_.as<uint8_t>() + ((12 * (nr + 2) + 15) & ~(size_t)15));
+            scan_tmp_.ensure(8 * (nbins / SCAN_TILE + 4));
+            EDSX_HIP(hipMemcpyAsync(&ctl->n, &nbins, 8, hipMemcpyHostToDevice, st));
+            const unsigned grid = (unsigned)std::min<u64>(ntiles, 1u << 16);
+            for (u32 pass = 0; pass < 8; pass++) {
+                const u64* kin = pass == 0 ? vt_pos_.as<u64>() : (pass & 1) ? tkeys : vt_s2_.as<u64>();
+                const u32* vin = pass == 0 ? nullptr : (pass & 1) ? tvals : vt_order_.as<u32>();
+                u64* kout = (pass & 1) ? vt_s2_.as<u64>() : tkeys;
+                u32* vout = (pass & 1) ? vt_order_.as<u32>() : tvals;
+                hipLaunchKernelGGL(k_rs_hist, dim3(grid), dim3(64), 0, st, kin, nr, 8 * pass, ntiles, table);
+                exclusive_scan_u64(table, table, &ctl->n, &ctl->nrec, scan_tmp_.as<u64>(), st);
+                hipLaunchKernelGGL(k_rs_scatter, dim3(grid), dim3(64), 0, st, kin, vin, nr, 8 * pass, ntiles, table, kout, vout);
+            }
+        }
         VtCtl z{};
         EDSX_HIP(hipMemcpyAsync(&ctl->t_alt, &z.t_alt, 8, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_vt_ascending, dim3(1024), dim3(256), 0, st, vt_s2_.as<u64>(), nr, ctl);   // sorted keys: strict?

@@ -82,3 +82,22 @@ def test_config2_full_size_eds2leds_linear(ctx):
     assert got[0] == want[0] and got[1] == want[1]
     st = ctx.eds_stats(got[0], got[1], 32)
     assert st["is_leds"] == 1
+
+
+def test_shuffled_records_take_the_device_radix_sort(ctx):
+    """A VCF whose records are in random order with pairwise distinct positions is ordered by the engine's own LSD radix
+    sort on the device (k_rs_hist / k_rs_scatter: eight stable passes of eight bits on (POS, record index) pairs); the
+    output must be the oracle's (the reference sorts with std::sort).  300 000 records of the configs[3] shape on a 30 Mb
+    reference, positions beyond one radix tile and digit."""
+    import random
+    vcf, fasta = ctx.genvcf(30_000_000, 300_000, 8, seed=9)
+    lines = vcf.split(b"\n")
+    head = [x for x in lines if x.startswith(b"#")]
+    body = [x for x in lines if x and not x.startswith(b"#")]
+    assert len(body) == 300_000
+    random.Random(3).shuffle(body)
+    shuffled = b"\n".join(head + body) + b"\n"
+    want = o.vcf(shuffled, fasta, 0)
+    got = ctx.vcf_transform(shuffled, fasta, 0)
+    assert got[0] == want[0] and got[1] == want[1]
+    assert got[0] == ctx.vcf_transform(vcf, fasta, 0)[0]              # the same records in file order
