@@ -380,6 +380,50 @@ __device__ __forceinline__ int fast_group(const MsaView& mv, u64 seg_a, u64 cmet
             if (mixed) return cref < 0x100u ? cref : (u32)mv.vc[(((u64)cs_hi << 32) | cs_lo) * (u64)mv.Spad + row];   // c == lane
             return (u32)cell_ptr(c)[row];
         };
+        if (mv.S <= 64u && !mixed) {
+            // Up to 64 rows: ONE ROW PER LANE instead of sixteen (of which four lanes would own rows).  A lane spells its
+            // row's gap-stripped string into LDS (64 bytes per lane), strings with the same length and 32-bit hash are
+            // compared with the first such row's string dword by dword (exact for every byte value), the groups come out in
+            // the order of their first rows.  The column-by-column refinement below costs a pass over the columns per
+            // distinct string - with few rows nearly every row is one (configs[1], 64 x 10 Mb: 0.245 -> see DESIGN).
+            const bool act = lane < mv.S;
+            u32* const mine32 = reinterpret_cast<u32*>(strs + lane * 64u);
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) *reinterpret_cast<uint4*>(mine32 + i) = make_uint4(0, 0, 0, 0);
+            u32 hsh = 2166136261u, len = 0, nul = 0, nl = 0;
+            for (u32 c = 0; c < ncol; c++) {
+                const u32 ch = act ? (u32)cell_ptr(c)[lane] : (u32)'-';
+                nul |= ch == 0 ? 1u : 0u;
+                const bool isnl = ch == '\n';
+                nl |= isnl ? 1u : 0u;
+                if (ch != '-' && !isnl) { strs[lane * 64u + len] = (uint8_t)ch; hsh = (hsh ^ ch) * 16777619u; len++; }
+            }
+            if (ballot64(act && nul)) return 0;                   // '\0' ends a row's string (msa_transforms.cpp:282): generic kernels
+            if (CHECK_NL && ballot64(act && nl)) saw_nl = 1;
+            u32 mygid = 0, rep = 0, k = 0, sum = 0;
+            u64 todo = ballot64(act);
+            while (todo) {
+                const int leader = __builtin_ctzll(todo);
+                const u32 lh = (u32)__builtin_amdgcn_readlane((int)hsh, leader), ll = (u32)__builtin_amdgcn_readlane((int)len, leader);
+                bool same = ((todo >> lane) & 1ull) && hsh == lh && len == ll;
+                const u32* lead32 = reinterpret_cast<const u32*>(strs + (u32)leader * 64u);
+                for (u32 i = 0; i < (ll + 3u) / 4u; i++) same = same && mine32[i] == lead32[i];      // (zero padding behind the strings)
+                const u64 m = ballot64(same);
+                if (same) mygid = k;
+                if (lane == k) rep = (u32)leader;
+                k++; sum += ll;
+                todo &= ~m;
+            }
+            uint32_t gb[4] = {0, 0, 0, 0};                        // group ids of rows 16 l .. 16 l + 15 for the lanes that own a record dword
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const u32 v = (u32)__shfl((int)mygid, (int)((lane * 16u + (u32)i) & 63u), 64);
+                gb[i >> 2] |= (v & 0xffu) << ((i & 3) * 8);
+            }
+            G.gid = make_uint4(gb[0], gb[1], gb[2], gb[3]);
+            G.k = k; G.sumlen = sum; G.rep = rep;
+            return 1;
+        }
         int r = refine_groups<16, CHECK_NL>(load_colx, cell, ncol, col0, lane, vmask, G, saw_nl, strs);
         if (r < 0) r = refine_groups<64, CHECK_NL>(load_colx, cell, ncol, col0, lane, vmask, G, saw_nl, strs);   // (rare: 17..64 raw groups)
         return r > 0 ? 1 : 0;

@@ -20,10 +20,6 @@ constexpr u32 RL_MAXCOLS = 16, RL_KMAX = 64, RL_UNROLL = 2;
 constexpr u32 RL_KEYS = 16, RL_TOT = RL_KEYS + 16 * RL_KMAX, RL_GID = 1344;
 __host__ __device__ inline u64 rl_stride_of(u32 S) { return ((u64)RL_GID + S + 63u) & ~(u64)63u; }
 
-__device__ __forceinline__ u64 readlane64(u64 v, int lane)
-{
-    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), lane) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, lane);
-}
 // letters of an exact key (non-zero bytes from byte 0 up)
 __device__ __forceinline__ u32 rl_key_len(u64 key) { return key ? (71u - (u32)__builtin_clzll(key)) / 8u : 0u; }
 

@@ -21,6 +21,10 @@ __device__ __forceinline__ u64 uniform64(u64 v)
            (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
 }
 __device__ __forceinline__ u32 uniform32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 readlane64(u64 v, int lane)
+{
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), lane) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, lane);
+}
 
 __device__ __forceinline__ u64 ld_relaxed(const u64* p)
 {
