@@ -152,6 +152,7 @@ int edsx_msa_plan_device(edsx_ctx* ctx, const uint8_t* d_msa, size_t msa_size, u
     return guarded(ctx, [&] {
         if (!d_msa || !eds_bytes || !seds_bytes) throw ParamError("null argument");
         ctx->msa.plan(d_msa, msa_size, context_len, static_cast<hipStream_t>(stream), eds_bytes, seds_bytes);
+        ctx->last_batches = 1;
     });
 }
 
@@ -167,7 +168,8 @@ int edsx_msa_last_batches(const edsx_ctx* ctx) { return ctx ? ctx->last_batches 
 
 int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info)
 {
-    if (!ctx || !info || !ctx->msa.planned()) return EDSX_ERR_INVALID_PARAMETER;
+    // (after a transform in column batches the pipeline holds the plan of the LAST batch only: no info then)
+    if (!ctx || !info || !ctx->msa.planned() || ctx->last_batches > 1) return EDSX_ERR_INVALID_PARAMETER;
     const MsaHdr& h = ctx->msa.header();
     info->n_rows = h.S; info->n_cols = h.L; info->line_width = h.lw ? h.lw : h.L;
     info->n_variant_cols = h.nv; info->n_segments = h.nseg; info->msa_bytes = ctx->msa.msa_bytes();

@@ -177,6 +177,8 @@ typedef struct {
     uint64_t n_rows, n_cols, line_width, n_variant_cols, n_segments, msa_bytes,
              n_slow_segments;   /* variant segments handled by the generic (slow) kernels */
 } edsx_msa_info;
+/* (EDSX_ERR_INVALID_PARAMETER when there is no plan, or the last transform ran in column batches: the numbers would be
+ * those of its last batch) */
 int edsx_msa_last_info(const edsx_ctx* ctx, edsx_msa_info* info);
 
 /* ---- multi-GPU column slabs: what the boundary stitch needs from a planned+emitted slab ----

@@ -452,6 +452,7 @@ def test_host_call_uploads_large_alignments_as_an_aligned_row_image(ctx):
 def test_column_batches_equal_the_single_call(ctx, K):
     """edsx_msa_transform_batched: K column batches one after the other through one pipeline, stitched like the slabs of
     the multi-GPU path (boundary columns straight from the host image).  l = 0 and l-EDS, one-line and wrapped rows."""
+    import edsparser_amd
     rng = random.Random(900 + K)
     cut = whole = 0
     for i in range(40):
@@ -464,6 +465,11 @@ def test_column_batches_equal_the_single_call(ctx, K):
         assert used in (1, K)
         cut += used == K
         whole += used == 1
+        if used == K:                                       # the pipeline holds the plan of the last batch only: no "last info"
+            with pytest.raises(edsparser_amd.EdsxError):
+                ctx.msa_info()
+        else:
+            assert ctx.msa_info()["n_cols"] > 0
     assert cut >= 25
     # not an alignment the geometry walk accepts: one piece, the transform words the error
     import edsparser_amd
