@@ -167,3 +167,27 @@ def test_msa2eds_cli_batches_option(tmp_path):
         assert "Column batches: " in r.stdout
     r = subprocess.run([os.path.join(BUILD, "msa2eds"), "-i", str(tmp_path / "x.msa"), "--batches", "0"], capture_output=True, text=True)
     assert r.returncode == 1 and "Error:" in r.stderr
+
+
+def test_anchor_info_equals_the_cpu_restatement():
+    """edsx_msa_anchor_info (the first / last common segment of at least l columns of a planned slab, with its text
+    offsets) against the same numbers derived on the CPU from the slab's rows and the oracle's text."""
+    import edsparser_amd
+    from test_multigpu_cpu import anchors_of, rows_of
+    ctx = edsparser_amd.Context(0)
+    rng = random.Random(41)
+    found = 0
+    for i in range(120):
+        l = rng.choice([1, 2, 4, 9, 30])
+        msa = random_msa(rng, S=rng.randint(2, 8), L=rng.randint(5, 500), lw=rng.choice([None, 7, 60]), p_var=rng.choice([0.02, 0.1, 0.4]))
+        eds, seds = ctx.msa_transform(msa, l)
+        assert (eds, seds) == o.msa(msa, l)
+        got = ctx.msa_anchor_info(l)
+        want = anchors_of(rows_of(msa), l, eds, seds)
+        if not want["found"]:
+            assert not got["found"], (i, l)
+            continue
+        found += 1
+        assert got == want, (i, l, got, want)
+    assert found > 60
+    ctx.close()
