@@ -162,7 +162,8 @@ __device__ u32 seg_row_len(const SegCells& sc, u64 a, u64 b, u32 r)
 // table and takes atomicMin(row) on its slot, so each group learns its first row in O(1) rounds
 // (the iterative path below needs one barrier round per distinct string).  Hashed keys are verified
 // byte for byte against the group's first row; a collision falls back to the iterative path.
-constexpr u32 HT_MAX_ROWS = 2048, HT_SIZE = 4096;
+constexpr u32 HT_MAX_ROWS = 4096, HT_SIZE = 8192;   // (4096 rows: 72 KB of row tables + 32 KB of table - one workgroup per CU)
+constexpr u32 HT_BM_WORDS = HT_MAX_ROWS / 32 + 8;
 // table entries for S rows: twice the rows, a power of two (1024 rows -> 2048 entries: two workgroups fit a CU)
 __host__ __device__ inline u32 ht_size_of(u32 S) { u32 n = 256; while (n < 2u * S) n <<= 1; return n < HT_SIZE ? n : HT_SIZE; }
 // one u32 per entry: while the rows insert themselves it holds the row that claimed the entry (keys are compared through
@@ -173,10 +174,10 @@ struct HtLds {
     {
         tabm = reinterpret_cast<u32*>(base);
         bm = reinterpret_cast<u32*>(base + (size_t)4 * hsz);
-        pre = bm + 72;
-        flag = pre + 72;
+        pre = bm + HT_BM_WORDS;
+        flag = pre + HT_BM_WORDS;
     }
-    __host__ __device__ static size_t bytes(u32 hsz) { return (size_t)4 * hsz + 4 * (72 + 72 + 8); }
+    __host__ __device__ static size_t bytes(u32 hsz) { return (size_t)4 * hsz + 4 * (HT_BM_WORDS + HT_BM_WORDS + 8); }
 };
 
 // returns k (number of distinct strings); fills lds.gid[], lds.rep_row[0..k)
@@ -234,7 +235,7 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLdsT<BIG>& lds,
         const u32 hsz = ht_size_of(S);
         HtLds ht(reinterpret_cast<uint8_t*>(lds.gid + ((S + 7) & ~7u)), hsz);
         for (u32 i = threadIdx.x; i < hsz; i += GT) ht.tabm[i] = 0xffffffffu;
-        for (u32 i = threadIdx.x; i < 72; i += GT) ht.bm[i] = 0;
+        for (u32 i = threadIdx.x; i < HT_BM_WORDS; i += GT) ht.bm[i] = 0;
         if (threadIdx.x == 0) *ht.flag = 0;
         __syncthreads();
         for (u32 r = threadIdx.x; r < S; r += GT) {
@@ -259,12 +260,17 @@ __device__ u32 group_segment(const MsaView& mv, u64 a, u64 b, SegLdsT<BIG>& lds,
         }
         __syncthreads();
         if (*ht.flag == 0) {
-            const u32 nwords = (S + 31) >> 5;                 // <= 64: one wave scans the first-row counts of the words
+            const u32 nwords = (S + 31) >> 5;                 // <= 128: one wave scans the first-row counts of the words, 64 at a time
             if (threadIdx.x < 64) {
-                const u32 c = threadIdx.x < nwords ? (u32)__builtin_popcount(ht.bm[threadIdx.x]) : 0u;
-                const u32 incl = wave_scan_incl(c);
-                if (threadIdx.x < nwords) ht.pre[threadIdx.x] = incl - c;
-                if (threadIdx.x == 63) *rep_sh = incl;
+                u32 carry = 0;
+                for (u32 w0 = 0; w0 < nwords; w0 += 64) {
+                    const u32 w = w0 + threadIdx.x;
+                    const u32 c = w < nwords ? (u32)__builtin_popcount(ht.bm[w]) : 0u;
+                    const u32 incl = wave_scan_incl(c);
+                    if (w < nwords) ht.pre[w] = carry + incl - c;
+                    carry += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+                if (threadIdx.x == 0) *rep_sh = carry;
             }
             __syncthreads();
             u32 myg[HT_MAX_ROWS / GT];

@@ -213,11 +213,11 @@ def test_baseline_config_64x10mb_bit_exact(ctx):
 
 
 @pytest.mark.parametrize("S", [2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513,
-                               959, 960, 961, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 4096, 8192])
+                               959, 960, 961, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8192])
 def test_row_count_boundaries(ctx, S):
     """Row counts around every layout switch: rows per lane 1/2/4/8/16 (vc pitch, K1 lane rows), the
     S <= 256 kernel instantiations, the last partial block of 64 rows, the fast/generic limit at 1024, the generic
-    kernels' hash-table limit at 2048 rows (two workgroups per CU below it) and the row limit of the build."""
+    kernels' hash-table limit at 4096 rows and the LDS limit of their row tables at 8192."""
     rng = random.Random(1000 + S)
     for lw in (None, 61):
         msa = random_msa(rng, S=S, L=2500, lw=lw, p_var=0.06)
