@@ -246,7 +246,9 @@ void MsaPipeline::plan_body(hipStream_t st)
     // rows per pass = T / CPR, tile width W = 16 * CPR columns.  Two workgroups per CU let one
     // tile's extraction phase overlap the other's load phase.
     // T = 512, RPT = 16: two workgroups per CU (1024 threads x 16 and 1024 x 8 were measured in round 1: slower).
-    const int T = 512, RPT = 16;
+    // 2049 .. 4096 rows: 1024 threads (one workgroup per CU) still hold 64-column tiles of all rows in registers; beyond
+    // that the rows are walked in a loop (twice: masks, then the variant bytes).
+    const int T = (S > 2048 && S <= 4096) ? 1024 : 512, RPT = 16;
     u32 cpr_log2 = 8;
     while (cpr_log2 > 2 && (u64)RPT * (T >> cpr_log2) < S) cpr_log2--;
     const bool hold = (u64)RPT * (T >> cpr_log2) >= S;
@@ -280,6 +282,7 @@ void MsaPipeline::plan_body(hipStream_t st)
     }
     launch_timer_begin("k_scan_extract", st);
     if (lane_rows && fuse_ && S <= 64) launch_k1<512, 16, true, true, 4, true>(kp, colbuf_bytes, st);   // one row per lane in the fused grouping
+    else if (lane_rows && T == 1024) launch_k1<1024, 16, true, true, 4>(kp, colbuf_bytes, st);
     else if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
     else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
     else if (big_) launch_k1<512, 16, false, false, 4, false, true>(kp, colbuf_bytes, st);
