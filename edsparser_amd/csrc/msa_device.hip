@@ -441,8 +441,9 @@ void MsaPipeline::plan_body(hipStream_t st)
         rl_.long_list = sp.long_list; rl_.long_count = sp.long_count;
         rl_.rec_stride = rl_stride_of((u32)S);
         rec_.ensure(((size_t)std::min<u64>(vc_cap_cols_, L / 2 + 2) + 2) * rl_.rec_stride);   // a record per variant segment (<= variant columns)
-        rl_.rec = rec_.as<uint8_t>(); rl_.eds = nullptr; rl_.seds = nullptr;
+        rl_.rec = rec_.as<uint8_t>(); rl_.eds = nullptr; rl_.seds = nullptr; rl_.next = &dh->rl_next;
         EDSX_HIP(hipMemsetAsync(&dh->slow_n, 0, 2 * sizeof(u64), st));
+        EDSX_HIP(hipMemsetAsync(&dh->rl_next, 0, sizeof(u64), st));
         TIMED("k_rl_count", st, hipLaunchKernelGGL(k_rl_count, dim3(persistent_grid(reinterpret_cast<const void*>(k_rl_count), 256, 0)),
                                                    dim3(256), 0, st, rl_));
         sp.gcache_stride = gc_stride_; sp.gcache_cap = 2 * gc_region_ / gc_stride_; sp.gcache = gcache_.as<uint8_t>();

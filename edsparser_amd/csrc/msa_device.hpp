@@ -98,6 +98,7 @@ struct MsaHdr {
     u64 long_n;        // common segments the variant emitters leave to k_emit_common_long (very long ones, and a final one)
     u64 heavy2_n;      // segments the light grouping kernel hands to a second heavy pass (other alphabets)
     u64 wide16_n;      // variant segments of 9..64 strings (wide_n: those of 5..8); adjacent to heavy2_n: cleared together
+    u64 rl_next;       // row-loop kernels: the next variant segment a wave takes
 };
 
 // One vc column holds the bytes of one variant column in NATURAL row order: byte r = row r, pitch =
@@ -156,6 +157,7 @@ struct RlParams {
     u64* long_list; u64* long_count;          // common segments for k_emit_common_long
     uint8_t* rec; u64 rec_stride;
     uint8_t* eds; uint8_t* seds;              // emit pass (eds_len / seds_len hold the offsets then)
+    u64* next;                                // work counter: the next variant segment (zeroed before each launch)
 };
 
 class MsaPipeline {

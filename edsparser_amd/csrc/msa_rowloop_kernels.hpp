@@ -18,7 +18,7 @@ namespace edsx {
 
 constexpr u32 RL_MAXCOLS = 16, RL_KMAX = 64, RL_UNROLL = 2;
 constexpr u32 RL_KEYS = 16, RL_TOT = RL_KEYS + 16 * RL_KMAX, RL_GID = 1344;
-__host__ __device__ inline u64 rl_stride_of(u32 S) { return ((u64)RL_GID + S + 63u) & ~(u64)63u; }
+__host__ __device__ inline u64 rl_stride_of(u32 S) { return ((u64)RL_GID + S + 16u + 63u) & ~(u64)63u; }   // (+16: a lane's last 16-byte store of group ids)
 
 // letters of an exact key (non-zero bytes from byte 0 up)
 __device__ __forceinline__ u32 rl_key_len(u64 key) { return key ? (71u - (u32)__builtin_clzll(key)) / 8u : 0u; }
@@ -51,8 +51,14 @@ __global__ void __launch_bounds__(256) k_rl_count(RlParams p)
         if (common_is_long(ncol)) p.long_list[atomicAdd(p.long_count, 1ull)] = seg;
     }
     const u32 lane = threadIdx.x & 63, S = mv.S;
-    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 vi = wave; vi < nvs; vi += nwaves) {
+    // The waves take the variant segments off a counter, one at a time: a segment of sixteen columns and dozens of strings
+    // costs fifty times one of a single SNP column, and with a fixed share per wave the kernel ended when the unluckiest
+    // wave did (SQ counters, 2000 rows x 2 M columns: 28 % of the wave slots busy on average).
+    while (true) {
+        u64 vi = 0;
+        if (lane == 0) vi = atomicAdd((unsigned long long*)p.next, 1ull);
+        vi = readlane64(vi, 0);
+        if (vi >= nvs) break;
         const u64 seg = 2 * vi + p0;
         const u64 a = uniform64(p.seg_start[seg]), b = uniform64(p.seg_start[seg + 1]);
         const u32 ncol = (u32)(b - a);
@@ -67,6 +73,62 @@ __global__ void __launch_bounds__(256) k_rl_count(RlParams p)
         u64 K = 0, K2 = 0;                                 // lane g: the key of string g (letters 0..7, 8..15)
         u32 TOT = 0, k = 0;                                // ... the bytes of its id list; strings so far (uniform)
         uint8_t* rec = p.rec + vi * p.rec_stride;
+        // ---- a single column (most variant segments): SIXTEEN rows per lane, 1024 per step - the column's bytes are
+        // compared with a string's letter sixteen at a time (byte-parallel, as in the kernels for up to 1024 rows), the
+        // "<id>," bytes of the matching rows are the byte sum of their lengths (v_sad_u8), and the group ids of a lane's
+        // rows go out as one 16-byte store.  ~70 instructions per string and 1024 rows instead of ~150 per 64 rows.
+        if (mine && ncol == 1u) {
+            const uint8_t* col0 = mv.vc + readlane64(colbase, 0);
+            for (u32 r0 = 0; r0 < S; r0 += 1024) {
+                const u32 nhere = S - r0 < 1024u ? S - r0 : 1024u;
+                const uint4 vmask = fast_valid_mask(lane, nhere);
+                const u32 off = r0 + lane * 16u;
+                const uint4 raw = load16u(col0 + (off + 16u <= mv.Spad ? off : mv.Spad - 16u));
+                if (ballot64(any_nul(raw, vmask))) { mine = false; break; }          // '\0' ends a row's string: generic
+                u32 nl_dummy = 0;
+                const uint4 col = normalise_col<true>(raw, vmask, nl_dummy);        // '-' (and a stray newline) -> 0: no letter
+                // "<id>," lengths of this lane's sixteen rows, a byte each
+                uint4 tlv;
+                {
+                    const u32 id0 = off + 1u;
+                    u32 p10 = 10, d = 1;
+                    while (id0 >= p10 && d < 9) { p10 *= 10; d++; }                  // p10: the first id with one digit more
+                    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const u32 id = id0 + (u32)i;
+                        const u32 tl = d + 1u + (id >= p10 ? 1u : 0u) + (id >= p10 * 10u ? 1u : 0u);   // (sixteen ids cross at most two powers of ten)
+                        w[i >> 2] |= tl << ((i & 3) * 8);
+                    }
+                    tlv = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                uint4 rm = vmask, gidv = make_uint4(0, 0, 0, 0);
+                auto take = [&](u32 letter, u32 g) {                                 // the remaining rows that spell `letter` join string g
+                    uint4 eq = bytes_eq_mask(col, letter * 0x01010101u);
+                    eq.x &= rm.x; eq.y &= rm.y; eq.z &= rm.z; eq.w &= rm.w;
+                    u32 bytes = __builtin_amdgcn_sad_u8(eq.x & tlv.x, 0u, 0u) + __builtin_amdgcn_sad_u8(eq.y & tlv.y, 0u, 0u) +
+                                __builtin_amdgcn_sad_u8(eq.z & tlv.z, 0u, 0u) + __builtin_amdgcn_sad_u8(eq.w & tlv.w, 0u, 0u);
+                    bytes = (u32)__builtin_amdgcn_readlane((int)wave_scan_incl(bytes), 63);
+                    if (lane == g) TOT += bytes;
+                    const u32 gg = g * 0x01010101u;
+                    gidv.x = (gidv.x & ~eq.x) | (eq.x & gg); gidv.y = (gidv.y & ~eq.y) | (eq.y & gg);
+                    gidv.z = (gidv.z & ~eq.z) | (eq.z & gg); gidv.w = (gidv.w & ~eq.w) | (eq.w & gg);
+                    rm.x &= ~eq.x; rm.y &= ~eq.y; rm.z &= ~eq.z; rm.w &= ~eq.w;
+                };
+                for (u32 g = 0; g < k; g++) take((u32)__builtin_amdgcn_readlane((int)(u32)K, (int)g), g);
+                int leader;
+                u32 i0;
+                while (first_remaining(rm, leader, i0)) {                             // new strings, in the order of their first rows
+                    if (k == RL_KMAX) { mine = false; break; }
+                    const u32 letter = leader_byte(col, leader, i0);
+                    if (lane == k) { K = letter; K2 = 0; TOT = 0; }
+                    take(letter, k);
+                    k++;
+                }
+                if (!mine) break;
+                if (lane * 16u < nhere) *reinterpret_cast<uint4*>(rec + RL_GID + off) = gidv;
+            }
+        } else
         // RL_UNROLL blocks of 64 rows per step: the column bytes of all of them are requested before the first block is
         // matched (four blocks per step measured no faster than one: the kernel is bound by its instructions)
         for (u32 r0 = 0; r0 < S && mine; r0 += 64 * RL_UNROLL) {
@@ -151,6 +213,8 @@ __global__ void __launch_bounds__(256) k_rl_emit(RlParams p)
     const u64 p0 = mv.vbit(0) ? 0 : 1;
     const u64 nvs = nseg > p0 ? (nseg - p0 + 1) / 2 : 0;
     const u32 lane = threadIdx.x & 63, S = mv.S;
+    // (a fixed share of the segments per wave here: taking them off a counter as k_rl_count does measured slower - 1.28 vs
+    // 1.0 ms - neighbouring segments write neighbouring text)
     const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 vi = wave; vi < nvs; vi += nwaves) {
         const u64 seg = 2 * vi + p0;
