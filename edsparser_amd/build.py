@@ -11,8 +11,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libedsx.so")
-SOURCES = ["msa_device.hip", "merge_device.hip", "vcf_device.hip", "synth.hip", "genrandom.hip", "genvcf.hip", "multi_gpu.hip", "capi.hip"]
+SOURCES = ["msa_device.hip", "msa_scan.hip", "merge_device.hip", "vcf_device.hip", "synth.hip", "genrandom.hip", "genvcf.hip", "multi_gpu.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# per-source flags.  msa_scan.hip: machine scheduler off - the column scan's loads stay in source order (bench shape: scan
+# 26.5 instead of 26.9 ms; the same flag on msa_device.hip costs its emitters 0.2 ms: alternating A/B runs, EXPERIMENTS.md)
+EXTRA_FLAGS = {"msa_scan.hip": ["-mllvm", "-enable-misched=false"]}
 # A second library for the tests only: the merge's final-text kernel with a 256-entry LDS stack and a 2-entry register stack
 # in its serial walk, so that ordinary inputs take the overflow -> serial walk -> HBM spill-stack path that otherwise needs
 # merge trees deeper than 96 (tests/test_merge_gpu.py::test_deep_tree_fallback_paths).  Never loaded by the product.
@@ -59,7 +62,7 @@ def build(force=False, verbose=False):
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            jobs.append((src, obj, []))
+            jobs.append((src, obj, EXTRA_FLAGS.get(s, [])))
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(lambda j: _compile(j[0], j[1], j[2], verbose), jobs))

@@ -26,14 +26,15 @@
 //                 bits, natural row order), number of strings, representative rows / the .eds text.
 //   eds_off/seds_off  exclusive scans of the per-segment text sizes.
 //
-// Source layout: this file is the host side (MsaPipeline: sizing, launches, timers) and the one translation unit of the
-// MSA kernels; the device code is in msa_wave.hpp (wave64 helpers, grouping primitives), msa_scan_kernels.hpp (row
-// index, column scan, runs -> segments), msa_generic_kernels.hpp (workgroup per segment, common text) and
+// Source layout: this file is the host side (MsaPipeline: sizing, launches, timers) and the translation unit of the
+// grouping / text kernels; the device code is in msa_wave.hpp (wave64 helpers, grouping primitives), msa_scan_kernels.hpp
+// (row index, column scan, runs -> segments: a translation unit of their own, msa_scan.hip, launched through
+// msa_scan_launch.hpp), msa_generic_kernels.hpp (workgroup per segment, common text) and
 // msa_fast_kernels.hpp (wave per segment, up to 1024 rows: tables, grouping, emitters) and msa_rowloop_kernels.hpp (wave
 // per segment, any number of rows).
 #include "msa_device.hpp"
 #include "msa_wave.hpp"
-#include "msa_scan_kernels.hpp"
+#include "msa_scan_launch.hpp"
 #include "msa_generic_kernels.hpp"
 #include "msa_fast_kernels.hpp"
 #include "msa_rowloop_kernels.hpp"
@@ -133,15 +134,6 @@ static const char* status_message(u64 st)
     return "MSA transform failed";
 }
 
-template <int T, int RPT, bool HOLD, bool LANEROWS, int MINW, bool ROWS64 = false, bool BIG = false>
-static void launch_k1(const K1Params& p, size_t lds, hipStream_t st)
-{
-    auto kern = k_scan_extract<T, RPT, HOLD, LANEROWS, MINW, ROWS64, BIG>;
-    EDSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.ntiles), dim3(T), lds, st, p);
-}
-
 void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t st,
                        uint64_t* eds_bytes, uint64_t* seds_bytes)
 {
@@ -159,14 +151,11 @@ void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t s
         rows_.ensure(sizeof(u64) * (row_cap + ROW_PAD));
         idx_tmp_.ensure(2 * sizeof(u64) * row_cap);
         EDSX_HIP(hipMemsetAsync(dh, 0, sizeof(MsaHdr), st));
-        TIMED("k_find_hdr_end", st, hipLaunchKernelGGL(k_find_hdr_end, dim3(1), dim3(64), 0, st, d_msa, (u64)n, dh));
-        TIMED("k_find_row0", st, hipLaunchKernelGGL(k_find_row0, dim3(512), dim3(1024), 0, st, d_msa, (u64)n, dh));
-        TIMED("k_index_spec", st, hipLaunchKernelGGL(k_index_spec, dim3(512), dim3(256), 0, st, d_msa, (u64)n, dh,
-                                                     idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + row_cap, row_cap));
-        TIMED("k_index_check", st, hipLaunchKernelGGL(k_index_check, dim3(1), dim3(1024), 0, st, d_msa, (u64)n, dh,
-                                                      idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + row_cap, rows_.as<u64>(), row_cap));
-        TIMED("k_index_rows", st, hipLaunchKernelGGL(k_index_rows, dim3(1), dim3(64), 0, st, d_msa, (u64)n, dh,
-                                                     rows_.as<u64>(), row_cap));
+        TIMED("k_find_hdr_end", st, launch_find_hdr_end(d_msa, (u64)n, dh, st));
+        TIMED("k_find_row0", st, launch_find_row0(d_msa, (u64)n, dh, st));
+        TIMED("k_index_spec", st, launch_index_spec(d_msa, (u64)n, dh, idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + row_cap, row_cap, st));
+        TIMED("k_index_check", st, launch_index_check(d_msa, (u64)n, dh, idx_tmp_.as<u64>(), idx_tmp_.as<u64>() + row_cap, rows_.as<u64>(), row_cap, st));
+        TIMED("k_index_rows", st, launch_index_rows(d_msa, (u64)n, dh, rows_.as<u64>(), row_cap, st));
         EDSX_HIP(hipMemcpyAsync(&h_, dh, sizeof(MsaHdr), hipMemcpyDeviceToHost, st));
         EDSX_HIP(hipStreamSynchronize(st));
         if (attempt == 0 && h_.status == ST_TOO_MANY_ROWS) {
@@ -180,7 +169,7 @@ void MsaPipeline::plan(const uint8_t* d_msa, size_t n, uint32_t l, hipStream_t s
     if (h_.S > MAX_ROWS) throw LimitError(status_message(ST_TOO_MANY_ROWS));
     {   // padding for the column scan's 16-row loads (at most 256 threads x 16 rows past the last one)
         const u64 padded = std::min<u64>(row_cap + ROW_PAD, (h_.S + 15) / 16 * 16 + 4096);
-        hipLaunchKernelGGL(k_pad_rows, dim3(4), dim3(256), 0, st, rows_.as<u64>(), h_.S, padded);
+        launch_pad_rows(rows_.as<u64>(), h_.S, padded, st);
     }
 
     const u64 Draw = h_.Draw;
@@ -281,41 +270,30 @@ void MsaPipeline::plan_body(hipStream_t st)
         kp.recf_stride = recf_stride_; kp.recf_gid = recf_gid_;
     }
     launch_timer_begin("k_scan_extract", st);
-    if (lane_rows && fuse_ && S <= 64) launch_k1<512, 16, true, true, 4, true>(kp, colbuf_bytes, st);   // one row per lane in the fused grouping
-    else if (lane_rows && T == 1024) launch_k1<1024, 16, true, true, 4>(kp, colbuf_bytes, st);
-    else if (lane_rows) launch_k1<512, 16, true, true, 4>(kp, colbuf_bytes, st);
-    else if (hold) launch_k1<512, 16, true, false, 4>(kp, colbuf_bytes, st);
-    else if (big_) launch_k1<512, 16, false, false, 4, false, true>(kp, colbuf_bytes, st);
-    else launch_k1<512, 16, false, false, 4>(kp, colbuf_bytes, st);
+    launch_scan_extract(kp, T, hold, lane_rows, /*rows64=*/lane_rows && fuse_ && S <= 64, big_, colbuf_bytes, st);
     launch_timer_end(st);
 
     const u64* V = lw ? v_.as<u64>() : vraw_.as<u64>();
-    if (lw) TIMED("k_vmap", st, hipLaunchKernelGGL(k_vmap, dim3(1024), dim3(256), 0, st, vraw_.as<u64>(),
-                                                   v_.as<u64>(), L, lw, nwords));
+    if (lw) TIMED("k_vmap", st, launch_vmap(vraw_.as<u64>(), v_.as<u64>(), L, lw, nwords, st));
 
     // ---- K2: runs -> segments
     u64* d_nwords = &dh->nwords;
-    TIMED("k_runstart_words", st, hipLaunchKernelGGL(k_runstart_words, dim3(1024), dim3(256), 0, st, V,
-                                                     hrun_.as<u64>(), cnt_.as<u64>(), L, nwords));
+    TIMED("k_runstart_words", st, launch_runstart_words(V, hrun_.as<u64>(), cnt_.as<u64>(), L, nwords, st));
     TIMED("scan_runs", st, exclusive_scan_u64(cnt_.as<u64>(), wbase_.as<u64>(), d_nwords, &dh->R,
                                               scan_tmp_.as<u64>(), st));
-    TIMED("k_write_runs", st, hipLaunchKernelGGL(k_write_positions, dim3(1024), dim3(256), 0, st, hrun_.as<u64>(),
-                                                 wbase_.as<u64>(), run_start_.as<u64>(), nwords, &dh->R, L));
+    TIMED("k_write_runs", st, launch_write_positions(hrun_.as<u64>(), wbase_.as<u64>(), run_start_.as<u64>(), nwords, &dh->R, L, st));
     const u64* seg_start; const u64* Hseg; const u64* segbase; const u64* d_nseg;
     if (l == 0) {
         seg_start = run_start_.as<u64>(); Hseg = hrun_.as<u64>(); segbase = wbase_.as<u64>(); d_nseg = &dh->R;
     } else {
-        TIMED("k_seg_flags", st, hipLaunchKernelGGL(k_seg_flags, dim3(1024), dim3(256), 0, st, run_start_.as<u64>(),
-                                                    V, &dh->R, (u64)l, flag_.as<u64>()));
+        TIMED("k_seg_flags", st, launch_seg_flags(run_start_.as<u64>(), V, &dh->R, (u64)l, flag_.as<u64>(), st));
         // eds_len_ doubles as scratch for the run-sized scan (it is overwritten by k_seg_count later)
         TIMED("scan_flags", st, exclusive_scan_u64(flag_.as<u64>(), eds_len_.as<u64>(), &dh->R, &dh->nseg,
                                                    scan_tmp_.as<u64>(), st));
         EDSX_HIP(hipMemsetAsync(hseg_.ptr, 0, 8 * (nwords + 1), st));
-        TIMED("k_write_segs", st, hipLaunchKernelGGL(k_write_segs, dim3(1024), dim3(256), 0, st, run_start_.as<u64>(),
-                                                     flag_.as<u64>(), eds_len_.as<u64>(), &dh->R, &dh->nseg,
-                                                     seg_start_.as<u64>(), hseg_.as<u64>(), L));
-        TIMED("k_popc_words", st, hipLaunchKernelGGL(k_popc_words, dim3(1024), dim3(256), 0, st, hseg_.as<u64>(),
-                                                     cnt_.as<u64>(), nwords));
+        TIMED("k_write_segs", st, launch_write_segs(run_start_.as<u64>(), flag_.as<u64>(), eds_len_.as<u64>(), &dh->R, &dh->nseg,
+                                                    seg_start_.as<u64>(), hseg_.as<u64>(), L, st));
+        TIMED("k_popc_words", st, launch_popc_words(hseg_.as<u64>(), cnt_.as<u64>(), nwords, st));
         TIMED("scan_segwords", st, exclusive_scan_u64(cnt_.as<u64>(), segbase_.as<u64>(), d_nwords, &dh->tmp_total,
                                                       scan_tmp_.as<u64>(), st));
         seg_start = seg_start_.as<u64>(); Hseg = hseg_.as<u64>(); segbase = segbase_.as<u64>(); d_nseg = &dh->nseg;

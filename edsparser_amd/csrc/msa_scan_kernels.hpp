@@ -1,8 +1,8 @@
 // msa_scan_kernels.hpp - row index (K0), column scan + fused grouping (K1), runs -> segments (K2)
-// included by msa_device.hip, which is the one translation unit of these kernels (the wave-level helpers are shared
-// between the column scan's fused grouping and the wave-per-segment kernels, and everything inlines).
+// included by msa_scan.hip, the translation unit of these kernels (msa_scan_launch.hpp is what the host side sees).
 #pragma once
 #include "msa_wave.hpp"
+#include "msa_scan_launch.hpp"
 
 namespace edsx {
 
@@ -225,21 +225,6 @@ __global__ void k_pad_rows(u64* __restrict__ row_start, u64 S, u64 n)
     for (u64 r = S + blockIdx.x * (u64)blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) row_start[r] = last;
 }
 
-// ---------------------------------------------------------------------------------------------
-// K1: column scan + variant-column extraction.  One workgroup owns a tile of W = 16*CPR raw
-// columns for ALL rows: T threads, thread (sub, j) holds the 16-byte chunk j of rows
-// sub, sub+RI, ... (RI = T/CPR) in registers, so each input byte is read from HBM once.
-//   msa_transforms.cpp:71-79  B[i] = 0 if c != ref[i] || c == '-'
-// ---------------------------------------------------------------------------------------------
-struct K1Params {
-    const uint8_t* file; const u64* row_start; MsaHdr* hdr;
-    u64* Vraw; u64* word_slot; uint8_t* vc; u64 vc_cap_cols;
-    u64 Draw, lw; u32 S, Spad, cpr_log2, cap_cols /* LDS colbuf capacity in columns */;
-    u64 ntiles;
-    // fused grouping (context length 0, one-line rows, S <= 1024): the variant runs that lie inside a tile are
-    // grouped right here, from the LDS image of the tile's variant columns; only the other columns go to vc
-    u32 fuse; u64* Fraw; u32* rec_info; uint8_t* recf; u32 recf_stride, recf_gid;
-};
 constexpr u32 FUSE_MAXW = 10;      // widest run grouped by the column scan (exact 3-bit-per-column keys in one dword; two-dword keys
                                    // for 11..20 columns spill 71 registers here - rounds 2 and 3)
 #ifndef EDSX_TAIL_WAVES
@@ -247,10 +232,6 @@ constexpr u32 FUSE_MAXW = 10;      // widest run grouped by the column scan (exa
 #endif
 constexpr u32 TAIL_WAVES = EDSX_TAIL_WAVES;   // waves of a scan workgroup that copy / group its variant columns (the rest retire early)
 constexpr u32 CLIST = 2048;        // variant columns per tile in fused mode (the LDS image holds at most 64 KB / 32 B columns)
-// fused record (indexed by the vc slot of the run's first column): group ids, 2 bits each (dword l = rows 16l..16l+15)
-// for up to 4 strings, 4 bits each (two dwords per lane) for 5..16; then at recf_gid: u32 k | textlen << 8, then the
-// .eds text "{s0,s1,..}" (<= REC_TEXT_MAX bytes).  rec_info[slot] = k | textlen << 8 | 4-bit ids << 30 | ok << 31
-constexpr u32 REC_TEXT_MAX = 64;
 
 
 
